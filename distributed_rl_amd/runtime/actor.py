@@ -1,0 +1,217 @@
+"""Actors (reference: ape_x/actor.py:9-102, r2d2/actor.py:10-91).
+
+One actor *process* drives ``E`` environments with one batched forward per step (E = 1 reproduces
+the reference's one-env-per-process actors). Per-env ε comes from the reference's ladder
+``0.4^(1+7·(i−1)/(N−1))`` evaluated over the global env index, so ``N`` processes × ``E`` envs
+explore like ``N·E`` reference actors (actor.py:66-69).
+
+Loop per env step (Ape-X): ε-greedy action → env.step → reward clip → n-step assembly → local buffer;
+when ≥ ``actor_batch`` transitions are buffered, compute their initial priorities with the local
+net (online == target, actor.py:93 — SURVEY Q3) and publish one binary block; every
+``actor_param_period`` env steps poll the parameter register (actor.py:101-102).
+R2D2 adds recurrent-state recording, overlapping sequence assembly and sequence priorities
+(r2d2/actor.py:39-87); pulling params also refreshes the actor-side target net (r2d2/actor.py:89-91).
+
+The inference function is pluggable: ``policy`` is either an ``nn.Module`` (CPU / oracle path) or an
+``engine.ActorEngine`` (gfx950 path: fused torso → head → ε-greedy with device-side RNG).
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from ..algo.nstep import NStepAssembler, SequenceAssembler, SequenceItem
+from ..config import ApexConfig, R2D2Config
+from ..models.packing import ParamPack
+from ..transport import ExperienceChannel, ParamChannel, codec
+from ..utils import epsilon_ladder
+
+
+class _LocalApexBuffer:
+    def __init__(self, capacity: int):
+        self.capacity = capacity
+        self.clear()
+
+    def clear(self):
+        self.state: List[np.ndarray] = []
+        self.next_state: List[np.ndarray] = []
+        self.action: List[int] = []
+        self.reward: List[float] = []
+        self.done: List[float] = []
+
+    def extend(self, b):
+        self.state.extend(b.state)
+        self.next_state.extend(b.next_state)
+        self.action.extend(b.action.tolist())
+        self.reward.extend(b.reward.tolist())
+        self.done.extend(b.done.tolist())
+        over = len(self.action) - self.capacity
+        if over > 0:                                      # bounded deque semantics (ReplayMemory(1000), actor.py:49)
+            for lst in (self.state, self.next_state, self.action, self.reward, self.done):
+                del lst[:over]
+
+    def __len__(self):
+        return len(self.action)
+
+    def take(self, n: int):
+        blk = dict(state=np.stack(self.state[:n]), next_state=np.stack(self.next_state[:n]),
+                   action=np.array(self.action[:n], dtype=np.int32), reward=np.array(self.reward[:n], dtype=np.float32),
+                   done=np.array(self.done[:n], dtype=np.float32))
+        for lst in (self.state, self.next_state, self.action, self.reward, self.done):
+            del lst[:n]
+        return blk
+
+
+class Actor:
+    def __init__(self, actor_no: int, env, policy_net, cfg, exp: ExperienceChannel, params: ParamChannel,
+                 metrics=None, num_total_actors: int = 4, device=torch.device("cpu"), target_net=None,
+                 heartbeat=None, seed: Optional[int] = None, render_every: int = 0):
+        self.no, self.env, self.cfg = actor_no, env, cfg
+        self.E = env.E
+        self.name = "actor_%d" % actor_no
+        self.net = policy_net
+        self.net.eval()
+        self.device = device
+        self.exp, self.params, self.metrics = exp, params, metrics
+        self.heartbeat = heartbeat
+        self.is_r2d2 = isinstance(cfg, R2D2Config)
+        self.eps = torch.from_numpy(epsilon_ladder(self.E, (actor_no - 1) * self.E + 1, num_total_actors * self.E))
+        self.rng = np.random.default_rng(seed if seed is not None else (os.getpid() * 7919 + actor_no))
+        self._pack = ParamPack.from_module(policy_net)
+        self._version = 0
+        self.target = target_net
+        if self.is_r2d2:
+            assert target_net is not None, "R2D2 actors carry a target net (r2d2/actor.py:21-23)"
+            self.target.load_state_dict(self.net.state_dict())
+            self.target.eval()
+            self.net.hx = torch.zeros(self.E, self.net.hidden, device=device)
+            self.net.cx = torch.zeros(self.E, self.net.hidden, device=device)
+            self.asm = SequenceAssembler(self.E, cfg.nstep, cfg.gamma, cfg.burn_in, cfg.seq_len, cfg.overlap,
+                                         cfg.reference_nstep_order, flush_tail=not cfg.reference_nstep_order)
+            self.local: List[SequenceItem] = []
+        else:
+            self.asm = NStepAssembler(self.E, cfg.nstep, cfg.gamma, cfg.reference_nstep_order,
+                                      flush_tail=not cfg.reference_nstep_order)
+            self.local = _LocalApexBuffer(cfg.actor_local_capacity)
+        self.env_steps = 0
+        self.published_blocks = 0
+        self.dropped_blocks = 0
+        self.episodes = 0
+        self.render_every = render_every
+
+    # ---- parameters -------------------------------------------------------------------------------
+    def pull_params(self) -> bool:
+        got = self.params.pull(self._version)
+        if got is None:
+            return False
+        self._version, flat = got
+        self._pack.flat.copy_(torch.from_numpy(flat))
+        self.net.load_state_dict(self._pack.state_dict(), strict=True)
+        if self.is_r2d2:
+            self.target.load_state_dict(self.net.state_dict())
+        return True
+
+    # ---- acting -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def act(self, obs_u8: np.ndarray) -> np.ndarray:
+        x = torch.from_numpy(obs_u8).to(self.device)
+        q = self.net(x).float().cpu()
+        greedy = q.argmax(1)
+        explore = torch.from_numpy(self.rng.random(self.E)) <= self.eps.double()     # random() > eps → greedy
+        rand = torch.from_numpy(self.rng.integers(0, q.shape[1], self.E))
+        return torch.where(explore, rand, greedy).numpy()
+
+    def _clip(self, r: np.ndarray) -> np.ndarray:
+        c = self.cfg.reward_clip
+        return np.clip(r, -c, c) if c is not None else r
+
+    # ---- publishing -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _publish_apex(self) -> None:
+        blk = self.local.take(self.cfg.actor_batch)
+        dev = self.device
+        td = self.net.td_batch(self.net, torch.from_numpy(blk["state"]).to(dev), torch.from_numpy(blk["action"]).to(dev),
+                               torch.from_numpy(blk["reward"]).to(dev), torch.from_numpy(blk["next_state"]).to(dev),
+                               torch.from_numpy(blk["done"]).to(dev), None, self.cfg.per_alpha, self.cfg.gamma_n)
+        blk["prio"] = td.prio.float().cpu().numpy()
+        self._send(blk, codec.KIND_APEX)
+
+    @torch.no_grad()
+    def _publish_r2d2(self) -> None:
+        seqs, self.local = self.local[:self.cfg.actor_batch], self.local[self.cfg.actor_batch:]
+        dev = self.device
+        frames = torch.from_numpy(np.stack([s.frames for s in seqs], 1)).to(dev)          # (T,K,…)
+        action = torch.from_numpy(np.stack([s.action for s in seqs], 1)).to(dev)
+        reward = torch.from_numpy(np.stack([s.reward for s in seqs], 1)).to(dev)
+        done = torch.from_numpy(np.stack([s.done for s in seqs], 1)).to(dev)
+        lengths = torch.tensor([s.length for s in seqs], device=dev)
+        h0 = torch.from_numpy(np.stack([s.h0 for s in seqs])).to(dev)
+        c0 = torch.from_numpy(np.stack([s.c0 for s in seqs])).to(dev)
+        td = self.net.sequence_td(self.target, frames, action, reward, done, lengths, h0, c0, None, self.cfg.eta,
+                                  self.cfg.gamma_n, self.cfg.rescale_eps, require_grad=False,
+                                  done_offset=self.cfg.nstep if self.cfg.reference_nstep_order else 0)
+        prio = td.prio.float().cpu().numpy()
+        T, H = seqs[0].frames.shape[0], seqs[0].h0.shape[0]
+        per = max(1, (getattr(self.exp, "slot_bytes", 1 << 62) - codec.HEADER_BYTES - 4096) //
+                  codec.r2d2_block_bytes(1, T, H, tuple(seqs[0].frames.shape[1:])))
+        for i in range(0, len(seqs), per):
+            part = seqs[i:i + per]
+            blk = dict(frames=np.stack([s.frames for s in part]), action=np.stack([s.action for s in part]).astype(np.int32),
+                       reward=np.stack([s.reward for s in part]), done=np.stack([s.done for s in part]),
+                       length=np.array([s.length for s in part], dtype=np.int32), h0=np.stack([s.h0 for s in part]),
+                       c0=np.stack([s.c0 for s in part]), prio=prio[i:i + per])
+            self._send(blk, codec.KIND_R2D2)
+
+    def _send(self, blk, kind) -> None:
+        for _ in range(200):                                 # bounded back-pressure wait (≈2 s), then drop
+            if self.exp.push(blk, kind, self.no, self.env_steps):
+                self.published_blocks += 1
+                return
+            time.sleep(0.01)
+        self.dropped_blocks += 1
+
+    # ---- main loop --------------------------------------------------------------------------------
+    def run(self, max_steps: Optional[int] = None, stop_event=None) -> None:
+        cfg = self.cfg
+        self.env.reset()
+        scores = np.zeros(self.E)
+        t = 0
+        while max_steps is None or t < max_steps:
+            if stop_event is not None and stop_event.is_set():
+                break
+            obs = self.env.current_obs()
+            if self.is_r2d2:
+                h_before = self.net.hx.detach().cpu().numpy()
+                c_before = self.net.cx.detach().cpu().numpy()
+            action = self.act(obs)
+            next_obs, reward, done, info = self.env.step(action)
+            scores += reward
+            r = self._clip(reward)
+            if self.is_r2d2:
+                self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
+                if done.any():
+                    self.net.reset(torch.from_numpy(done))
+            else:
+                out = self.asm.step(obs, action, r, next_obs, done)
+                if out is not None:
+                    self.local.extend(out)
+            if done.any():
+                for e in np.nonzero(done)[0]:
+                    self.episodes += 1
+                    if self.metrics is not None:
+                        self.metrics.scalar("Score %s" % self.name, self.episodes, scores[e])
+                    scores[e] = 0.0
+            if self.metrics is not None and self.render_every and t % self.render_every == 0:
+                self.metrics.image("Frame %s" % self.name, obs[0][..., -1])
+            while len(self.local) >= cfg.actor_batch:
+                self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
+            t += 1
+            self.env_steps += self.E
+            if t % cfg.actor_param_period == 0:
+                self.pull_params()
+            if self.heartbeat is not None and t % 16 == 0:
+                self.heartbeat.tick(self.env_steps)

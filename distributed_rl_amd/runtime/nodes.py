@@ -1,0 +1,154 @@
+"""Process entrypoints behind ``actor_node.py`` / ``learner_node.py`` (reference: actor_node.py:8-37,
+learner_node.py:11-47). The reference's flags are kept verbatim (``-n -e -a -t -r -v`` / ``-e -a -r -v -d -s``);
+new flags select the transport (shm by default — no Redis needed on one node), the number of envs
+per actor process, the execution engine and bounded runs for tests.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+import torch.optim as optim
+
+from .. import envs
+from ..config import make_config
+from ..models import DuelingDQN, DuelingLSTMDQN
+from ..obs import make_metrics
+from ..transport import connect, shm_names
+
+
+def _common(parser):
+    parser.add_argument('-e', '--env', type=str, default='MultiFrameBreakout-v0', help='Environment name.')
+    parser.add_argument('-a', '--algorithm', type=str, default='ape_x', choices=['ape_x', 'r2d2'], help='Select an algorithm.')
+    parser.add_argument('-r', '--redisserver', type=str, default='localhost', help="Redis's server name (transport=redis).")
+    parser.add_argument('-v', '--visdomserver', type=str, default='', help="Visdom's server name ('' = no visdom sink).")
+    parser.add_argument('--transport', type=str, default=os.environ.get('DRL_TRANSPORT', 'shm'), choices=['shm', 'redis', 'inproc'])
+    parser.add_argument('--run-id', type=str, default=os.environ.get('DRL_RUN_ID', 'default'), help='Namespace of the shm segments.')
+    parser.add_argument('--max-steps', type=int, default=None, help='Stop after this many steps (default: run forever).')
+    parser.add_argument('--seed', type=int, default=None)
+    parser.add_argument('--log-dir', type=str, default='', help='Write JSONL metrics here.')
+    parser.add_argument('--quiet', action='store_true')
+    parser.add_argument('--device', type=str, default='', help="'' = cuda if available else cpu.")
+
+
+def _device(name: str) -> torch.device:
+    if name:
+        return torch.device(name)
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def _heartbeat(args, role, ident):
+    if args.transport != 'shm':
+        return None
+    try:
+        from .heartbeat import HeartbeatTable
+        return HeartbeatTable(shm_names(args.run_id)[2], create=False).register(role, ident)
+    except OSError:
+        return None
+
+
+def actor_main(argv=None) -> int:
+    parser = argparse.ArgumentParser(description='Actor process for distributed reinforcement.')
+    parser.add_argument('-n', '--no', type=int, default=1, help='Actor number.')
+    parser.add_argument('-t', '--num_total_actors', type=int, default=4, help='Total number of actors.')
+    parser.add_argument('--num-envs', type=int, default=int(os.environ.get('DRL_NUM_ENVS', '1')), help='Envs per actor process.')
+    parser.add_argument('--actor-batch', type=int, default=None)
+    parser.add_argument('--param-period', type=int, default=None)
+    _common(parser)
+    args = parser.parse_args(argv)
+    from .actor import Actor
+    device = _device(args.device)
+    cfg = make_config(args.algorithm, actor_batch=args.actor_batch, actor_param_period=args.param_period)
+    env = envs.make_vec(args.env, args.num_envs, seed=args.seed)
+    metrics = make_metrics("actor_%d" % args.no, args.visdomserver, args.log_dir, args.quiet)
+    exp, par = connect(args.transport, args.run_id, create=False, host=args.redisserver)
+    hb = _heartbeat(args, "actor", args.no)
+    if args.algorithm == 'ape_x':
+        net = DuelingDQN(env.n_action).to(device)
+        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, heartbeat=hb, seed=args.seed)
+    else:
+        net = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)
+        tgt = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)
+        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, target_net=tgt,
+                      heartbeat=hb, seed=args.seed)
+    actor.pull_params()
+    try:
+        actor.run(max_steps=args.max_steps)
+    except KeyboardInterrupt:
+        pass
+    finally:
+        if hb is not None:
+            hb.close()
+    return 0
+
+
+def learner_main(argv=None) -> int:
+    parser = argparse.ArgumentParser(description='Learner process for distributed reinforcement.')
+    parser.add_argument('-d', '--actordevice', type=str, default='', help="Actor's device (kept for compatibility).")
+    parser.add_argument('-s', '--replaysize', type=int, default=100000, help="Replay memory size.")
+    parser.add_argument('--save-dir', type=str, default='./models')
+    parser.add_argument('--resume', type=str, default='', help='model_<t>.pth to resume from.')
+    parser.add_argument('--batch-size', type=int, default=None)
+    parser.add_argument('--start-memory-size', type=int, default=None)
+    parser.add_argument('--save-timing', type=int, default=None)
+    parser.add_argument('--target-update', type=int, default=None)
+    parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
+                        help='torch = ATen learner; hip = graph-captured gfx950 engine (needs a GPU).')
+    parser.add_argument('--ring-slots', type=int, default=64)
+    parser.add_argument('--ring-slot-mb', type=int, default=8)
+    _common(parser)
+    args = parser.parse_args(argv)
+    device = _device(args.device)
+    cfg = make_config(args.algorithm, batch_size=args.batch_size, start_memory_size=args.start_memory_size,
+                      save_timing=args.save_timing, target_update=args.target_update)
+    n_action = envs.n_action_of(args.env)             # the reference builds a whole env just for this (learner_node.py:20)
+    metrics = make_metrics("learner", args.visdomserver, args.log_dir, args.quiet)
+    exp, par = connect(args.transport, args.run_id, create=True, host=args.redisserver,
+                       n_slots=args.ring_slots, slot_bytes=args.ring_slot_mb << 20)
+    hb_table, hb = None, None
+    if args.transport == 'shm':
+        from .heartbeat import HeartbeatTable
+        try:
+            hb_table = HeartbeatTable(shm_names(args.run_id)[2], create=False)
+        except OSError:
+            hb_table = HeartbeatTable(shm_names(args.run_id)[2], create=True)
+        hb = hb_table.register("learner", 0)
+    engine = args.engine
+    if engine == 'auto':
+        engine = 'hip' if device.type == 'cuda' else 'torch'
+    try:
+        if engine == 'hip':
+            from ..engine.learner import run_hip_learner
+            return run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device)
+        from .learner import Learner, load_checkpoint
+        if args.algorithm == 'ape_x':
+            model, target = DuelingDQN(n_action).to(device), DuelingDQN(n_action).to(device)
+            opt = optim.RMSprop(model.parameters(), lr=cfg.lr, alpha=cfg.rms_alpha, eps=cfg.rms_eps)     # learner_node.py:28
+        else:
+            model = DuelingLSTMDQN(n_action, cfg.batch_size, cfg.burn_in, cfg.nstep).to(device)
+            target = DuelingLSTMDQN(n_action, cfg.batch_size, cfg.burn_in, cfg.nstep).to(device)
+            opt = optim.Adam(model.parameters(), lr=cfg.lr, eps=cfg.adam_eps)                             # learner_node.py:40
+        start = load_checkpoint(args.resume, model, target, opt) if args.resume else 0
+        learner = Learner(model, target, opt, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb,
+                          sync_target=not args.resume)
+        learner.publish()
+        try:
+            learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir, start_step=start)
+        except KeyboardInterrupt:
+            pass
+        finally:
+            learner.close()
+    finally:
+        if hb is not None:
+            hb.close()
+        exp.close()
+        par.close()
+        if hb_table is not None:
+            hb_table.close()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(learner_main() if 'learner' in sys.argv[0] else actor_main())

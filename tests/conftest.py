@@ -1,0 +1,16 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture
+def run_id():
+    import uuid
+    return "t" + uuid.uuid4().hex[:10]
