@@ -1,0 +1,105 @@
+// Shared device helpers for the gfx950 kernels. Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DRL_API extern "C" __attribute__((visibility("default")))
+#define WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 (NaN stays NaN: quiet bit forced)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        float t = __shfl_up(v, o, WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (result valid in every thread)
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats */) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    float t = (threadIdx.x < nw) ? smem[threadIdx.x] : 0.f;
+    if (w == 0) { t = wave_sum(t); if (lane == 0) smem[16] = t; }
+    __syncthreads();
+    return smem[16];
+}
+__device__ __forceinline__ float block_max(float v, float* smem) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    float t = (threadIdx.x < nw) ? smem[threadIdx.x] : -3.0e38f;
+    if (w == 0) { t = wave_max(t); if (lane == 0) smem[16] = t; }
+    __syncthreads();
+    return smem[16];
+}
+
+// Philox-4x32-10 counter RNG (device-side ε-greedy and PER sampling; no host RNG on the hot path)
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ uint4 operator()(uint64_t ctr, uint64_t stream) const {
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n1 = (uint32_t)p1;
+            uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+// uint32 -> uniform float in [0,1)
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Device-resident per-step scalars, advanced on device so a captured graph needs no host arguments.
+struct StepState {
+    unsigned long long step;     // learner step t
+    unsigned long long rng_ctr;  // Philox counter
+    float beta;                  // IS exponent at this step
+    float beta0, beta_inc;       // beta = min(1, beta0 + beta_inc * t)
+    float total_prio;            // root of the tree at sample time
+    long long n_items;           // live items at sample time
+    float loss;                  // last loss (written by the TD kernel)
+    float grad_norm;             // last global grad norm (written by the optimizer)
+    float max_w;                 // max IS weight of the last batch (pre-normalisation)
+    float pad;
+};
+

@@ -1,0 +1,181 @@
+// Dueling head: FC 512->A (advantage) + FC 512->1 (value) + combine + (optionally) batched epsilon-greedy,
+// and its backward (reference: libs/models.py:26-29,101-104, libs/utils.py:36-41).
+//
+// Input is the post-ReLU hidden row h[1024] (bf16) written by the fused FC1 GEMM epilogue: h[0:512] = adv
+// branch, h[512:1024] = val branch. N = A+1 <= 19 outputs is far too narrow for an MFMA tile, so one wave owns
+// one row: 16 elements per lane, A+1 running dot products, wave-wide reductions, and the combine / argmax /
+// epsilon-greedy draw in the same wave — Q never takes a second kernel, and actor inference ends here with the
+// action already selected on device (per-env epsilon vector, Philox RNG; no host `random`).
+#include "common.h"
+
+#define MAX_A 32
+#define HID 512
+
+__device__ __forceinline__ void load16_bf16(const bf16_t* p, float* out) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+// grid = ceil(M/4), block = 256 (4 rows per block)
+__global__ __launch_bounds__(256) void k_head_fwd(const bf16_t* __restrict__ h, int M, int A, const bf16_t* __restrict__ w_adv,
+                                                 const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
+                                                 const float* __restrict__ b_val, float* __restrict__ q_out,
+                                                 int* __restrict__ action_out, const float* __restrict__ eps, int eps_mod,
+                                                 unsigned long long seed, const unsigned long long* __restrict__ ctr_ptr) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float hv[16];
+    load16_bf16(h + (long long)row * (2 * HID) + lane * 16, hv);
+    const bool adv_half = lane < 32;
+    const int k0 = (lane & 31) * 16;
+    float wv[16];
+    float val = 0.f;
+    if (!adv_half) {
+        load16_bf16(w_val + k0, wv);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) val += hv[i] * wv[i];
+    }
+    val = wave_sum(val) + b_val[0];
+    float my_q = 0.f, adv_sum = 0.f;       // lane j keeps adv_j
+    for (int j = 0; j < A; ++j) {
+        float acc = 0.f;
+        if (adv_half) {
+            load16_bf16(w_adv + (long long)j * HID + k0, wv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += hv[i] * wv[i];
+        }
+        acc = wave_sum(acc) + (b_adv ? b_adv[j] : 0.f);
+        adv_sum += acc;
+        if (lane == j) my_q = acc;
+    }
+    my_q = val + my_q - adv_sum / (float)A;
+    if (lane < A) q_out[(long long)row * A + lane] = my_q;
+    if (action_out) {
+        // argmax (first max wins, like torch.argmax) over lanes [0,A)
+        float best = lane < A ? my_q : -3.0e38f;
+        int bi = lane < A ? lane : MAX_A + 64;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, WAVE);
+            int oi = __shfl_xor(bi, o, WAVE);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            int act = bi;
+            if (eps) {
+                Philox ph(seed);
+                uint4 r = ph(ctr_ptr ? *ctr_ptr : 0ull, (unsigned long long)row);
+                float e = eps[eps_mod > 0 ? row % eps_mod : row];
+                if (!(u01(r.x) > e)) { int ra = (int)(u01(r.y) * (float)A); act = ra < A ? ra : A - 1; }   // utils.py:37
+            }
+            action_out[row] = act;
+        }
+    }
+}
+
+// dh[row][k] = relu'(h) * (k<512 ? sum_j dadv_j W_adv[j][k] : dval W_val[k-512]);  one wave per row.
+__global__ __launch_bounds__(256) void k_head_bwd_dh(const float* __restrict__ dq, const bf16_t* __restrict__ h, int M, int A,
+                                                    const bf16_t* __restrict__ w_adv, const bf16_t* __restrict__ w_val,
+                                                    bf16_t* __restrict__ dh) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float g = lane < A ? dq[(long long)row * A + lane] : 0.f;
+    const float dval = wave_sum(g);
+    const float dadv_mine = g - dval / (float)A;     // lane j holds dadv_j
+    float hv[16], wv[16], acc[16];
+    load16_bf16(h + (long long)row * (2 * HID) + lane * 16, hv);
+    const bool adv_half = lane < 32;
+    const int k0 = (lane & 31) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float dj = __shfl(dadv_mine, j, WAVE);
+        if (adv_half) {
+            load16_bf16(w_adv + (long long)j * HID + k0, wv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += dj * wv[i];
+        }
+    }
+    if (!adv_half) {
+        load16_bf16(w_val + k0, wv);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = dval * wv[i];
+    }
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = pack_bf2(hv[2 * i] > 0.f ? acc[2 * i] : 0.f, hv[2 * i + 1] > 0.f ? acc[2 * i + 1] : 0.f);
+    uint4* d = reinterpret_cast<uint4*>(dh + (long long)row * (2 * HID) + lane * 16);
+    d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// Weight grads, accumulated with fp32 atomics into ZEROED buffers.
+// grid = (4, ceil(M/128)); block = 256: thread owns hidden column k = blockIdx.x*256 + tid of the 1024.
+__global__ __launch_bounds__(256) void k_head_bwd_dw(const float* __restrict__ dq, const bf16_t* __restrict__ h, int M, int A,
+                                                    float* __restrict__ gw_adv, float* __restrict__ gb_adv /* may be null */,
+                                                    float* __restrict__ gw_val, float* __restrict__ gb_val) {
+    __shared__ float s_d[128][MAX_A + 1];    // [r][0..A-1] = dadv, [r][A] = dval
+    const int r0 = blockIdx.y * 128;
+    const int nr = min(128, M - r0);
+    for (int i = threadIdx.x; i < 128 * (A + 1); i += 256) {
+        int r = i / (A + 1), j = i % (A + 1);
+        float v = 0.f;
+        if (r < nr) {
+            const float* q = dq + (long long)(r0 + r) * A;
+            float s = 0.f;
+            for (int t = 0; t < A; ++t) s += q[t];
+            v = (j < A) ? q[j] - s / (float)A : s;
+        }
+        s_d[r][j] = v;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;     // 0..1023
+    const bool adv_half = k < HID;
+    float acc[MAX_A];
+#pragma unroll
+    for (int j = 0; j < MAX_A; ++j) acc[j] = 0.f;
+    float accv = 0.f;
+    for (int r = 0; r < nr; ++r) {
+        const float hv = bf2f(h[(long long)(r0 + r) * (2 * HID) + k]);
+        if (adv_half) {
+#pragma unroll
+            for (int j = 0; j < MAX_A; ++j) if (j < A) acc[j] += s_d[r][j] * hv;
+        } else {
+            accv += s_d[r][A] * hv;
+        }
+    }
+    if (adv_half) {
+#pragma unroll
+        for (int j = 0; j < MAX_A; ++j) if (j < A) atomicAdd(&gw_adv[(long long)j * HID + k], acc[j]);
+    } else {
+        atomicAdd(&gw_val[k - HID], accv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= A) {
+        float s = 0.f;
+        for (int r = 0; r < nr; ++r) s += s_d[r][threadIdx.x];
+        if (threadIdx.x < A) { if (gb_adv) atomicAdd(&gb_adv[threadIdx.x], s); }
+        else atomicAdd(&gb_val[0], s);
+    }
+}
+
+DRL_API int drl_head_fwd(const void* h, int M, int A, const void* w_adv, const float* b_adv, const void* w_val, const float* b_val,
+                         float* q_out, int* action_out, const float* eps, int eps_mod, unsigned long long seed,
+                         const unsigned long long* ctr_ptr, hipStream_t s) {
+    if (M <= 0 || A <= 0 || A > MAX_A) return -1;
+    k_head_fwd<<<(M + 3) / 4, 256, 0, s>>>((const bf16_t*)h, M, A, (const bf16_t*)w_adv, b_adv, (const bf16_t*)w_val, b_val, q_out,
+                                           action_out, eps, eps_mod, seed, ctr_ptr);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_head_bwd(const float* dq, const void* h, int M, int A, const void* w_adv, const void* w_val, void* dh,
+                         float* gw_adv, float* gb_adv, float* gw_val, float* gb_val, hipStream_t s) {
+    if (M <= 0 || A <= 0 || A > MAX_A) return -1;
+    k_head_bwd_dh<<<(M + 3) / 4, 256, 0, s>>>(dq, (const bf16_t*)h, M, A, (const bf16_t*)w_adv, (const bf16_t*)w_val, (bf16_t*)dh);
+    k_head_bwd_dw<<<dim3(4, (M + 127) / 128), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
+    return (int)hipGetLastError();
+}

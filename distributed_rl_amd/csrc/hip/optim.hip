@@ -1,0 +1,136 @@
+// Fused global-norm clip + optimizer + bf16 re-cast over ONE flat parameter buffer (SURVEY G11, G12, G17;
+// reference: clip_grad_norm_(…,40) ape_x/learner.py:77, RMSprop learner_node.py:28, Adam learner_node.py:40).
+//
+// All parameters / gradients / optimizer moments live back to back in flat fp32 buffers (models/packing.py), so
+// the 14-17 per-tensor launches of a framework optimizer collapse to two: a partial sum-of-squares pass and an
+// update pass that (a) finishes the norm reduction in-block, (b) derives the clip coefficient, (c) applies the
+// update to the fp32 master weights and (d) writes the bf16 copy the MFMA kernels read — so there is no separate
+// cast pass and no host synchronisation for the norm.
+#include "common.h"
+
+#define NPART 1024
+
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+    __shared__ float red[32];
+    float acc = 0.f;
+    const long long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = g4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__device__ __forceinline__ float clip_coef_from_partials(const float* __restrict__ partial, int n_partial, float grad_scale,
+                                                         float max_norm, float* red, float* norm_out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += blockDim.x) acc += partial[i];
+    acc = block_sum(acc, red);
+    const float norm = sqrtf(acc) * grad_scale;
+    *norm_out = norm;
+    return max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+}
+
+// mode 0: RMSprop (alpha, eps; no momentum, not centered).  mode 1: Adam (beta1, beta2, eps, bias correction).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
+                                                 float* __restrict__ m2, bf16_t* __restrict__ p_bf16, long long n,
+                                                 const float* __restrict__ partial, int n_partial, float grad_scale,
+                                                 float max_norm, float lr, float a1, float a2, float eps, StepState* st) {
+    __shared__ float red[32];
+    float norm;
+    const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm) * grad_scale;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && st) st->grad_norm = norm;
+    float bc1 = 1.f, bc2s = 1.f;
+    if (MODE == 1) {
+        const float t = (float)(st->step + 1);
+        bc1 = 1.0f - __powf(a1, t);
+        bc2s = sqrtf(1.0f - __powf(a2, t));
+    }
+    const long long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m14 = reinterpret_cast<float4*>(m1);
+    float4* m24 = reinterpret_cast<float4*>(m2);
+    uint2* pb4 = reinterpret_cast<uint2*>(p_bf16);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pv = p4[i], gv = g4[i];
+        float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
+        if (MODE == 0) {
+            float4 sv = m14[i];
+            float se[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                se[k] = a1 * se[k] + (1.0f - a1) * ge[k] * ge[k];
+                pe[k] -= lr * ge[k] / (sqrtf(se[k]) + eps);
+            }
+            m14[i] = make_float4(se[0], se[1], se[2], se[3]);
+        } else {
+            float4 mv = m14[i], vv = m24[i];
+            float me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                me[k] = a1 * me[k] + (1.0f - a1) * ge[k];
+                ve[k] = a2 * ve[k] + (1.0f - a2) * ge[k] * ge[k];
+                pe[k] -= (lr / bc1) * me[k] / (sqrtf(ve[k]) / bc2s + eps);
+            }
+            m14[i] = make_float4(me[0], me[1], me[2], me[3]);
+            m24[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+        }
+        p4[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+        if (p_bf16) pb4[i] = make_uint2(pack_bf2(pe[0], pe[1]), pack_bf2(pe[2], pe[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    uint2* d4 = reinterpret_cast<uint2*>(dst);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = s4[i];
+        d4[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+    if (blockIdx.x == 0) for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) dst[i] = f2bf(src[i]);
+}
+
+static int grid_for(long long n) {
+    long long b = (n / 4 + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > NPART) b = NPART;
+    return (int)b;
+}
+
+DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART floats */, int* n_partial_out, hipStream_t s) {
+    if (n <= 0 || (n & 3)) return -1;       // flat buffers are padded to 64 elements
+    int grid = grid_for(n);
+    k_sumsq_partial<<<grid, 256, 0, s>>>(g, n, partial);
+    if (n_partial_out) *n_partial_out = grid;
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_rmsprop_step(float* p, const float* g, float* sq, void* p_bf16, long long n, const float* partial,
+                             int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
+                             hipStream_t s) {
+    if (n <= 0 || (n & 3)) return -1;
+    k_opt_step<0><<<grid_for(n), 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
+                                              lr, alpha, 0.f, eps, (StepState*)st);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const float* partial,
+                          int n_partial, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                          void* st, hipStream_t s) {
+    if (n <= 0 || (n & 3) || !st) return -1;
+    k_opt_step<1><<<grid_for(n), 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
+                                              beta1, beta2, eps, (StepState*)st);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_cast_bf16(const float* src, void* dst, long long n, hipStream_t s) {
+    if (n <= 0) return -1;
+    k_cast_bf16<<<grid_for(n), 256, 0, s>>>(src, (bf16_t*)dst, n);
+    return (int)hipGetLastError();
+}

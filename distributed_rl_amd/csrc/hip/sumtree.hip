@@ -1,0 +1,188 @@
+// HBM-resident prioritized-replay sum-tree for gfx950 (reference semantics: libs/sumtree.py).
+//
+// Design (wave64-first, not a translation of the reference's pointer-based binary tree):
+//   * 64-ary tree: one wave loads a node's 64 children with one coalesced 256-B read, so 2 M leaves are
+//     4 levels (2^21 -> 2^15 -> 2^9 -> 8) instead of 21 dependent loads of a binary descent.
+//   * Sampling draws a FRESH uniform per level (u_l ~ U[0, S_node)) and picks the child by a wave-wide
+//     inclusive scan + ballot. P(leaf) = prod_l (child/parent) = p_leaf / total exactly, and no residual is
+//     carried down, so fp32 sums of 2 M priorities lose nothing at the leaf level. Draws are independent
+//     and with replacement, like the reference (sumtree.py:133-137). A zero-priority leaf is never returned
+//     (the reference can crash on that float edge, sumtree.py:57-61).
+//   * Updates scatter leaves, then recompute every touched parent FROM ITS 64 CHILDREN level by level
+//     (never +=delta), so there is no float drift (sumtree.py:20-26). Duplicate indices recompute the same
+//     node to the same value -> deterministic.
+//   * The tree is a ring: ingest overwrites the oldest slots (FIFO eviction, replay_memory.py:70-75) and
+//     bumps a per-slot generation; priority write-backs carry the generation they sampled and are dropped
+//     if the slot was overwritten meanwhile.
+#include "common.h"
+
+#define MAX_LEVELS 6
+
+struct TreeDesc {
+    float* base;
+    int n_levels;               // level 0 = leaves ... level n_levels-1 = top (<= 64 nodes)
+    long long off[MAX_LEVELS];  // element offset of each level inside base
+    long long cap;              // number of leaf slots (ring capacity)
+};
+
+__global__ void k_step_begin(StepState* st, const long long* n_items) {
+    if (threadIdx.x == 0) {
+        unsigned long long t = st->step;
+        st->beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
+        st->n_items = *n_items;
+        st->rng_ctr += 1;
+    }
+}
+__global__ void k_step_end(StepState* st) {
+    if (threadIdx.x == 0) st->step += 1;
+}
+
+// One wave per draw.
+__global__ __launch_bounds__(256) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
+                                               int* __restrict__ idx_out, float* __restrict__ prio_out,
+                                               const int* __restrict__ gen, int* __restrict__ gen_out,
+                                               long long* __restrict__ frame_off, long long frame_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;   // whole wave exits together
+    Philox ph(seed);
+    const unsigned long long ctr = st->rng_ctr;
+    uint4 r = ph(ctr, (unsigned long long)b);
+    uint32_t rnd[4] = {r.x, r.y, r.z, r.w};
+    long long node = 0;
+    float leaf_p = 0.f;
+    for (int lvl = tr.n_levels - 1, k = 0; lvl >= 0; --lvl, ++k) {
+        if (k == 4) { r = ph(ctr, (unsigned long long)b + ((unsigned long long)1 << 40)); rnd[0] = r.x; rnd[1] = r.y; rnd[2] = r.z; rnd[3] = r.w; k = 0; }
+        float v = tr.base[tr.off[lvl] + node * 64 + lane];
+        float incl = wave_scan_incl(v, lane);
+        float S = __shfl(incl, 63, WAVE);
+        if (lvl == tr.n_levels - 1 && b == 0 && lane == 0) st->total_prio = S;
+        float u = u01(rnd[k]) * S;
+        unsigned long long hit = __ballot(incl > u && v > 0.f);
+        unsigned long long nz = __ballot(v > 0.f);
+        int pick;
+        if (hit) pick = __ffsll((long long)hit) - 1;
+        else if (nz) pick = 63 - __clzll((long long)nz);          // float edge: take the last non-empty child
+        else pick = 0;                                             // empty tree
+        leaf_p = __shfl(v, pick, WAVE);
+        node = node * 64 + pick;
+    }
+    if (lane == 0) {
+        int i = (int)(node < tr.cap ? node : tr.cap - 1);
+        idx_out[b] = i;
+        prio_out[b] = leaf_p;
+        if (gen_out) gen_out[b] = gen ? gen[i] : 0;
+        if (frame_off) {                                   // byte offsets of s and s' in the frame store
+            frame_off[b] = (long long)i * frame_bytes;
+            frame_off[B + b] = ((long long)tr.cap + i) * frame_bytes;
+        }
+    }
+}
+
+// Leaves <- new priorities (dropped when the slot generation changed since sampling).
+__global__ void k_set_leaves(TreeDesc tr, const int* __restrict__ idx, const float* __restrict__ val, int n,
+                             const int* __restrict__ gen, const int* __restrict__ gen_expected) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = idx[i];
+    if (s < 0 || s >= tr.cap) return;
+    if (gen && gen_expected && gen[s] != gen_expected[i]) return;
+    tr.base[tr.off[0] + s] = val[i];
+}
+
+// Recompute parents at `level` (>=1) of the given leaf indices from their 64 children. One wave per index.
+__global__ __launch_bounds__(256) void k_fix_level(TreeDesc tr, int level, const int* __restrict__ idx, int n) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int s = idx[i];
+    if (s < 0 || s >= tr.cap) return;
+    long long node = (long long)s >> (6 * level);
+    float v = tr.base[tr.off[level - 1] + node * 64 + lane];
+    v = wave_sum(v);
+    if (lane == 0) tr.base[tr.off[level] + node] = v;
+}
+
+// Ring ingest: slots [start, start+n) mod cap get new priorities and a new generation.
+__global__ void k_ingest(TreeDesc tr, long long start, int n, const float* __restrict__ prio,
+                         int* __restrict__ gen, int* __restrict__ idx_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long s = (start + i) % tr.cap;
+    tr.base[tr.off[0] + s] = prio[i];
+    if (gen) gen[s] += 1;
+    idx_out[i] = (int)s;
+}
+
+// Generic row gather: dst[i] = src[byte offset off[i]], rows of row_bytes (multiple of 16).
+__global__ __launch_bounds__(256) void k_gather_rows(const uint8_t* __restrict__ src, const long long* __restrict__ off,
+                                                    uint8_t* __restrict__ dst, int row_bytes) {
+    const uint4* s = reinterpret_cast<const uint4*>(src + off[blockIdx.x]);
+    uint4* d = reinterpret_cast<uint4*>(dst + (long long)blockIdx.x * row_bytes);
+    for (int k = threadIdx.x; k < row_bytes / 16; k += blockDim.x) d[k] = s[k];
+}
+
+template <typename T>
+__global__ void k_gather_scalar(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ dst, int n, int inner) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * inner) return;
+    dst[i] = src[(long long)idx[i / inner] * inner + (i % inner)];
+}
+
+static TreeDesc make_desc(float* base, int n_levels, const long long* off, long long cap) {
+    TreeDesc d;
+    d.base = base; d.n_levels = n_levels; d.cap = cap;
+    for (int i = 0; i < MAX_LEVELS; ++i) d.off[i] = i < n_levels ? off[i] : 0;
+    return d;
+}
+
+DRL_API int drl_step_begin(void* st, const long long* n_items, hipStream_t s) {
+    k_step_begin<<<1, 64, 0, s>>>((StepState*)st, n_items);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_step_end(void* st, hipStream_t s) {
+    k_step_end<<<1, 64, 0, s>>>((StepState*)st);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, long long cap, void* st,
+                               unsigned long long seed, int B, int* idx_out, float* prio_out, const int* gen,
+                               int* gen_out, long long* frame_off, long long frame_bytes, hipStream_t s) {
+    if (n_levels < 1 || n_levels > MAX_LEVELS || B <= 0) return -1;
+    TreeDesc d = make_desc(base, n_levels, off, cap);
+    k_sample<<<(B + 3) / 4, 256, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes);
+    return (int)hipGetLastError();
+}
+
+// set leaves + recompute all ancestor levels
+DRL_API int drl_sumtree_update(float* base, int n_levels, const long long* off, long long cap, const int* idx,
+                               const float* val, int n, const int* gen, const int* gen_expected, hipStream_t s) {
+    if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0) return -1;
+    TreeDesc d = make_desc(base, n_levels, off, cap);
+    k_set_leaves<<<(n + 255) / 256, 256, 0, s>>>(d, idx, val, n, gen, gen_expected);
+    for (int l = 1; l < n_levels; ++l) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, l, idx, n);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_sumtree_ingest(float* base, int n_levels, const long long* off, long long cap, long long start, int n,
+                               const float* prio, int* gen, int* idx_scratch, hipStream_t s) {
+    if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0 || n > cap) return -1;
+    TreeDesc d = make_desc(base, n_levels, off, cap);
+    k_ingest<<<(n + 255) / 256, 256, 0, s>>>(d, start, n, prio, gen, idx_scratch);
+    for (int l = 1; l < n_levels; ++l) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, l, idx_scratch, n);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_gather_rows(const void* src, const long long* off, void* dst, int row_bytes, int n, hipStream_t s) {
+    if (row_bytes % 16 != 0 || n <= 0) return -1;
+    k_gather_rows<<<n, 256, 0, s>>>((const uint8_t*)src, off, (uint8_t*)dst, row_bytes);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_gather_f32(const float* src, const int* idx, float* dst, int n, int inner, hipStream_t s) {
+    k_gather_scalar<float><<<(n * inner + 255) / 256, 256, 0, s>>>(src, idx, dst, n, inner);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_gather_i32(const int* src, const int* idx, int* dst, int n, int inner, hipStream_t s) {
+    k_gather_scalar<int><<<(n * inner + 255) / 256, 256, 0, s>>>(src, idx, dst, n, inner);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,47 @@
+"""ctypes signatures of libdrl_hip.so (csrc/hip/*.hip). Every entry point returns a hipError_t-style int."""
+from ctypes import c_float, c_int, c_longlong, c_ulonglong, c_void_p, POINTER
+
+P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
+LP = POINTER(c_longlong)
+
+SIGS = {
+    # sumtree.hip
+    "drl_step_begin": [P, P, P],
+    "drl_step_end": [P, P],
+    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P],
+    "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P],
+    "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P],
+    "drl_gather_rows": [P, P, P, I, I, P],
+    "drl_gather_f32": [P, P, P, I, I, P],
+    "drl_gather_i32": [P, P, P, I, I, P],
+    # td.hip
+    "drl_apex_td": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, I, P, P, P, P, P],
+    "drl_is_weights": [P, I, P, F, P, P],
+    "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
+    # optim.hip
+    "drl_grad_sumsq": [P, L, P, POINTER(c_int), P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, P],
+    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, P],
+    "drl_cast_bf16": [P, P, L, P],
+    # head.hip
+    "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],
+    "drl_head_bwd": [P, P, I, I, P, P, P, P, P, P, P, P],
+    # gemm.hip
+    "drl_gemm": [I, I, P, L, P, L, I, I, I, P, L, P, P, L, F, I, I, P],
+    "drl_conv_fwd": [I, P, P, I, P, P, P, I, P],
+    "drl_conv_wgrad": [I, P, P, I, P, P, I, P],
+    "drl_conv_dcol": [I, P, I, P, P, P],
+    # conv_bwd.hip
+    "drl_col2im": [I, P, P, P, I, P],
+    "drl_colsum": [P, I, I, P, P],
+    "drl_relu_mask": [P, P, P, L, P],
+}
+
+
+def declare(lib) -> None:
+    for name, args in SIGS.items():
+        if not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args

@@ -1,0 +1,247 @@
+"""Thin Python entry points of the gfx950 kernels (csrc/hip). Tensors must already live on the GPU, be
+contiguous and of the documented dtype; launches go to torch's *current* stream, so they can be captured into
+a ``torch.cuda.CUDAGraph`` (a hipGraph) together with RCCL collectives. There is deliberately no PyTorch
+fallback here: if ``libdrl_hip.so`` is missing these raise (oracle implementations live in ops/oracle.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from .. import native
+
+EPI_RELU, EPI_OUT_F32, EPI_ATOMIC, EPI_MASK = 1, 2, 4, 8
+NT, NN, TN = 0, 1, 2
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ck(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> None:
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError("%s must be a contiguous CUDA %s tensor (got %s, contiguous=%s, device=%s)"
+                        % (name, dtype, t.dtype, t.is_contiguous(), t.device))
+
+
+# ---- step state ---------------------------------------------------------------------------------------
+STEP_STATE_BYTES = 64
+
+
+def new_step_state(device, beta0: float, beta_decay: int) -> torch.Tensor:
+    """64-byte device struct (csrc/hip/common.h StepState): step, rng_ctr, beta, beta0, beta_inc, total_prio,
+    n_items, loss, grad_norm, max_w."""
+    import struct
+    raw = struct.pack("<QQffff", 0, 0, beta0, beta0, (1.0 - beta0) / beta_decay, 0.0)
+    host = bytearray(STEP_STATE_BYTES)
+    host[:len(raw)] = raw
+    return torch.frombuffer(host, dtype=torch.uint8).clone().to(device)
+
+
+def read_step_state(st: torch.Tensor) -> dict:
+    import struct
+    b = bytes(st.cpu().numpy().tobytes())
+    step, ctr, beta, beta0, beta_inc, total = struct.unpack_from("<QQffff", b, 0)
+    n_items, = struct.unpack_from("<q", b, 32)
+    loss, gnorm, max_w = struct.unpack_from("<fff", b, 40)
+    return dict(step=step, rng_ctr=ctr, beta=beta, beta0=beta0, beta_inc=beta_inc, total_prio=total, n_items=n_items,
+                loss=loss, grad_norm=gnorm, max_w=max_w)
+
+
+def step_begin(st: torch.Tensor, n_items: torch.Tensor) -> None:
+    _ck(native.hip().drl_step_begin(_p(st), _p(n_items), _s()), "step_begin")
+
+
+def step_end(st: torch.Tensor) -> None:
+    _ck(native.hip().drl_step_end(_p(st), _s()), "step_end")
+
+
+# ---- sum-tree -----------------------------------------------------------------------------------------
+class TreeLayout:
+    """64-ary sum-tree over ``capacity`` leaves inside one flat fp32 buffer."""
+
+    def __init__(self, capacity: int):
+        self.capacity = int(capacity)
+        sizes, n = [], self.capacity
+        while True:
+            padded = (n + 63) // 64 * 64
+            sizes.append(padded)
+            if n <= 64:
+                break
+            n = (n + 63) // 64
+        self.sizes = sizes
+        self.n_levels = len(sizes)
+        offs, o = [], 0
+        for s in sizes:
+            offs.append(o)
+            o += s
+        self.offsets = offs
+        self.total = o
+        self.c_off = (ctypes.c_longlong * 6)(*(offs + [0] * (6 - len(offs))))
+
+
+def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
+                   prio_out: torch.Tensor, gen: Optional[torch.Tensor] = None, gen_out: Optional[torch.Tensor] = None,
+                   frame_off: Optional[torch.Tensor] = None, frame_bytes: int = 0) -> None:
+    B = idx_out.numel()
+    _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
+    if frame_off is not None:
+        _chk(frame_off, torch.int64, "frame_off")
+        assert frame_off.numel() >= 2 * B
+    _ck(native.hip().drl_sumtree_sample(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(st), seed, B, _p(idx_out),
+                                        _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), frame_bytes, _s()), "sumtree_sample")
+
+
+def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
+                   gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None) -> None:
+    _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
+    assert idx.numel() == val.numel()
+    _ck(native.hip().drl_sumtree_update(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(idx), _p(val), idx.numel(),
+                                        _p(gen), _p(gen_expected), _s()), "sumtree_update")
+
+
+def sumtree_ingest(tree: torch.Tensor, lay: TreeLayout, start: int, prio: torch.Tensor, gen: Optional[torch.Tensor],
+                   idx_scratch: torch.Tensor) -> None:
+    _chk(prio, torch.float32, "prio"); _chk(idx_scratch, torch.int32, "idx_scratch")
+    assert idx_scratch.numel() >= prio.numel()
+    _ck(native.hip().drl_sumtree_ingest(_p(tree), lay.n_levels, lay.c_off, lay.capacity, int(start), prio.numel(), _p(prio),
+                                        _p(gen), _p(idx_scratch), _s()), "sumtree_ingest")
+
+
+def gather_rows(src: torch.Tensor, off: torch.Tensor, dst: torch.Tensor, row_bytes: int) -> None:
+    _chk(off, torch.int64, "off")
+    assert dst.numel() * dst.element_size() >= off.numel() * row_bytes
+    _ck(native.hip().drl_gather_rows(_p(src), _p(off), _p(dst), row_bytes, off.numel(), _s()), "gather_rows")
+
+
+# ---- TD ------------------------------------------------------------------------------------------------
+def apex_td(q_on, q_tg, idx, act, rew, done, p_sampled, st, gamma_n, alpha, prio_eps, dq, new_prio,
+            delta_out=None, w_out=None, n_scale: float = 1.0, use_is: bool = True) -> None:
+    B, A = q_tg.shape
+    assert q_on.shape == (2 * B, A) and dq.shape == (B, A)
+    for t, n in ((q_on, "q_on"), (q_tg, "q_tg"), (rew, "rew"), (done, "done"), (dq, "dq"), (new_prio, "new_prio")):
+        _chk(t, torch.float32, n)
+    _chk(act, torch.int32, "act")
+    _ck(native.hip().drl_apex_td(_p(q_on), _p(q_tg), B, A, _p(idx), _p(act), _p(rew), _p(done), _p(p_sampled), _p(st),
+                                 gamma_n, alpha, prio_eps, n_scale, 1 if use_is else 0, _p(dq), _p(new_prio), _p(delta_out),
+                                 _p(w_out), _s()), "apex_td")
+
+
+def is_weights(p_sampled, st, w_out, n_scale: float = 1.0) -> None:
+    _ck(native.hip().drl_is_weights(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(w_out), _s()), "is_weights")
+
+
+def r2d2_td(q_on, q_tg, idx, act, rew, done, lengths, w, st, burn_in, nstep, done_offset, gamma_n, eta, rs_eps, dq,
+            new_prio, seq_loss=None) -> None:
+    T, B, A = q_on.shape
+    for t, n in ((q_on, "q_on"), (q_tg, "q_tg"), (rew, "rew"), (done, "done"), (dq, "dq"), (new_prio, "new_prio")):
+        _chk(t, torch.float32, n)
+    _chk(act, torch.int32, "act"); _chk(lengths, torch.int32, "lengths")
+    _ck(native.hip().drl_r2d2_td(_p(q_on), _p(q_tg), T, B, A, _p(idx), _p(act), _p(rew), _p(done), _p(lengths), _p(w), _p(st),
+                                 burn_in, nstep, done_offset, gamma_n, eta, rs_eps, _p(dq), _p(new_prio), _p(seq_loss), _s()),
+        "r2d2_td")
+
+
+# ---- optimizer -----------------------------------------------------------------------------------------
+def n_partials(n: int) -> int:
+    return max(1, min(1024, (n // 4 + 255) // 256))
+
+
+def grad_sumsq(g: torch.Tensor, partial: torch.Tensor) -> int:
+    _chk(g, torch.float32, "g"); _chk(partial, torch.float32, "partial")
+    assert partial.numel() >= 1024
+    n = ctypes.c_int()
+    _ck(native.hip().drl_grad_sumsq(_p(g), g.numel(), _p(partial), ctypes.byref(n), _s()), "grad_sumsq")
+    return n.value
+
+
+def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st) -> None:
+    _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
+                                      max_norm, lr, alpha, eps, _p(st), _s()), "rmsprop_step")
+
+
+def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st) -> None:
+    _ck(native.hip().drl_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
+                                   max_norm, lr, b1, b2, eps, _p(st), _s()), "adam_step")
+
+
+def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
+    _chk(src, torch.float32, "src"); _chk(dst, torch.bfloat16, "dst")
+    _ck(native.hip().drl_cast_bf16(_p(src), _p(dst), src.numel(), _s()), "cast_bf16")
+
+
+# ---- head ----------------------------------------------------------------------------------------------
+def head_fwd(h, w_adv, b_adv, w_val, b_val, q_out, action_out=None, eps=None, eps_mod: int = 0, seed: int = 0,
+             ctr: Optional[torch.Tensor] = None) -> None:
+    M, A = q_out.shape
+    _chk(h, torch.bfloat16, "h"); _chk(q_out, torch.float32, "q_out")
+    assert h.shape == (M, 1024) and w_adv.shape == (A, 512)
+    _ck(native.hip().drl_head_fwd(_p(h), M, A, _p(w_adv), _p(b_adv), _p(w_val), _p(b_val), _p(q_out), _p(action_out), _p(eps),
+                                  eps_mod, seed, _p(ctr), _s()), "head_fwd")
+
+
+def head_bwd(dq, h, w_adv, w_val, dh, gw_adv, gb_adv, gw_val, gb_val) -> None:
+    M, A = dq.shape
+    _chk(dq, torch.float32, "dq"); _chk(h, torch.bfloat16, "h"); _chk(dh, torch.bfloat16, "dh")
+    _ck(native.hip().drl_head_bwd(_p(dq), _p(h), M, A, _p(w_adv), _p(w_val), _p(dh), _p(gw_adv), _p(gb_adv), _p(gw_val),
+                                  _p(gb_val), _s()), "head_bwd")
+
+
+# ---- GEMM / conv ---------------------------------------------------------------------------------------
+def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N: int, K: int, bias=None, mask=None,
+         scale: float = 1.0, flags: int = 0, splits: int = 1, big: Optional[bool] = None, lda=None, ldb=None, ldc=None) -> None:
+    """mode NT: c[M,N] = a[M,K]·b[N,K]ᵀ; NN: c = a[M,K]·b[K,N]; TN: c = a[K,M]ᵀ·b[K,N]. a/b bf16; c bf16 or f32 (flag)."""
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    want = torch.float32 if flags & EPI_OUT_F32 else torch.bfloat16
+    _chk(c, want, "c")
+    lda = a.shape[-1] if lda is None else lda
+    ldb = b.shape[-1] if ldb is None else ldb
+    ldc = c.shape[-1] if ldc is None else ldc
+    if big is None:
+        big = (N % 128 == 0) and (M >= 2048) and (mode != TN or M % 128 == 0)
+    ldm = mask.shape[-1] if mask is not None else 0
+    _ck(native.hip().drl_gemm(mode, 1 if big else 0, _p(a), lda, _p(b), ldb, M, N, K, _p(c), ldc, _p(bias), _p(mask), ldm,
+                              scale, flags, splits, _s()), "gemm")
+
+
+def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
+             frame_off: Optional[torch.Tensor] = None, relu: bool = True) -> None:
+    _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
+    _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
+    _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out), 1 if relu else 0, _s()),
+        "conv_fwd")
+
+
+def conv_wgrad(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, frames: int,
+               frame_off: Optional[torch.Tensor] = None, splits: int = 64) -> None:
+    _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw")
+    _ck(native.hip().drl_conv_wgrad(layer, _p(x), _p(frame_off), frames, _p(dy), _p(dw), splits, _s()), "conv_wgrad")
+
+
+def conv_dcol(layer: int, dy: torch.Tensor, w: torch.Tensor, dcol: torch.Tensor, frames: int) -> None:
+    _chk(dy, torch.bfloat16, "dy"); _chk(w, torch.bfloat16, "w"); _chk(dcol, torch.bfloat16, "dcol")
+    _ck(native.hip().drl_conv_dcol(layer, _p(dy), frames, _p(w), _p(dcol), _s()), "conv_dcol")
+
+
+def col2im(layer: int, dcol: torch.Tensor, act_in: torch.Tensor, dx: torch.Tensor, frames: int) -> None:
+    _ck(native.hip().drl_col2im(layer, _p(dcol), _p(act_in), _p(dx), frames, _s()), "col2im")
+
+
+def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
+    _chk(dy, torch.bfloat16, "dy"); _chk(db, torch.float32, "db")
+    _ck(native.hip().drl_colsum(_p(dy), M, N, _p(db), _s()), "colsum")
+
+
+def relu_mask(a: torch.Tensor, mask: torch.Tensor, out: torch.Tensor) -> None:
+    _ck(native.hip().drl_relu_mask(_p(a), _p(mask), _p(out), a.numel(), _s()), "relu_mask")

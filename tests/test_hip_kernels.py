@@ -1,0 +1,396 @@
+"""Numerics of every gfx950 kernel against a plain PyTorch fp32 reference of the same op.
+All tests need a real MI355X and the in-tree libdrl_hip.so (no fallback: a missing library fails loudly)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from distributed_rl_amd.ops import oracle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from distributed_rl_amd.ops import hip as H
+    from distributed_rl_amd import native
+    native.hip()          # raises if the extension was not built
+    return H
+
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).contiguous()
+
+
+# ---- sum-tree ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cap", [100, 5000, 300_000])
+def test_sumtree_ingest_total_sample_update(hip, cap):
+    H = hip
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    gen = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    scratch = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(cap)
+    n = cap * 3 // 4
+    prio = torch.rand(n, generator=g) + 0.01
+    prio[::7] = 0.0
+    H.sumtree_ingest(tree, lay, 0, prio.to(DEV), gen, scratch)
+    st = H.new_step_state(DEV, 0.4, 1000)
+    n_items = torch.tensor([n], dtype=torch.int64, device=DEV)
+    B = 4096
+    idx = torch.zeros(B, dtype=torch.int32, device=DEV)
+    p = torch.zeros(B, device=DEV)
+    counts = np.zeros(cap, dtype=np.int64)
+    rounds = 40
+    for r in range(rounds):
+        H.step_begin(st, n_items)
+        H.sumtree_sample(tree, lay, st, 1234, idx, p)
+        i = idx.cpu().numpy()
+        assert np.allclose(p.cpu().numpy(), prio.numpy()[i])          # returned priority is the leaf's
+        counts += np.bincount(i, minlength=cap)
+    s = H.read_step_state(st)
+    assert s["total_prio"] == pytest.approx(float(prio.double().sum()), rel=1e-5)
+    assert s["rng_ctr"] == rounds and s["n_items"] == n
+    assert counts[n:].sum() == 0 and counts[:n][prio.numpy() == 0].sum() == 0   # never an empty / zero leaf
+    # distribution: compare aggregated over 64 equal-count buckets (chi-square, 63 dof)
+    order = np.argsort(prio.numpy())
+    buckets = np.array_split(order, 64)
+    obs = np.array([counts[b].sum() for b in buckets], dtype=np.float64)
+    exp = np.array([prio.numpy()[b].sum() for b in buckets], dtype=np.float64)
+    exp = exp / exp.sum() * obs.sum()
+    keep = exp > 5
+    chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+    assert chi2 < 140, chi2
+    # update with duplicates + stale generation
+    ui = torch.tensor([3, 3, 10, 11], dtype=torch.int32, device=DEV)
+    uv = torch.tensor([5.0, 5.0, 7.0, 9.0], device=DEV)
+    ge = gen[ui.long()].clone()
+    ge[3] += 1                                                          # slot 11 "was overwritten since sampling"
+    H.sumtree_update(tree, lay, ui, uv, gen, ge)
+    ref = prio.clone()
+    ref[3], ref[10] = 5.0, 7.0
+    leaves = tree[:cap].cpu()
+    assert torch.equal(leaves[:n], ref)
+    H.step_begin(st, n_items)
+    H.sumtree_sample(tree, lay, st, 1, idx, p)
+    assert H.read_step_state(st)["total_prio"] == pytest.approx(float(ref.double().sum()), rel=1e-5)
+    # every level is the exact fp32 sum of its 64 children (no drift)
+    t = tree.cpu()
+    for lvl in range(1, lay.n_levels):
+        child = t[lay.offsets[lvl - 1]:lay.offsets[lvl - 1] + lay.sizes[lvl - 1]].view(-1, 64)
+        par = t[lay.offsets[lvl]:lay.offsets[lvl] + child.shape[0]]
+        assert torch.allclose(par, child.sum(1), rtol=1e-6, atol=0)
+    # ring wrap-around ingest bumps generations and overwrites the oldest slots
+    H.sumtree_ingest(tree, lay, cap - 2, torch.tensor([1.5, 2.5, 3.5, 4.5], device=DEV), gen, scratch)
+    leaves = tree[:cap].cpu()
+    assert leaves[cap - 2] == 1.5 and leaves[cap - 1] == 2.5 and leaves[0] == 3.5 and leaves[1] == 4.5
+    assert gen[0].item() == 2 and gen[cap - 1].item() == 1 + (1 if cap - 1 < n else 0)
+
+
+def test_gather_rows(hip):
+    src = torch.randint(0, 256, (50, 28224), dtype=torch.uint8, device=DEV)
+    off = (torch.tensor([4, 0, 49, 4, 17], dtype=torch.int64, device=DEV) * 28224)
+    dst = torch.zeros(5, 28224, dtype=torch.uint8, device=DEV)
+    hip.gather_rows(src, off, dst, 28224)
+    assert torch.equal(dst, src[[4, 0, 49, 4, 17]])
+
+
+# ---- TD kernels ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,A", [(1, 4), (50, 6), (512, 4), (512, 18), (1500, 9)])
+def test_apex_td(hip, B, A):
+    H = hip
+    g = torch.Generator().manual_seed(B * 31 + A)
+    cap = 4 * B + 7
+    q_on, q_tg = torch.randn(2 * B, A, generator=g), torch.randn(B, A, generator=g)
+    idx = torch.randint(0, cap, (B,), generator=g).int()
+    act, rew = torch.randint(0, A, (cap,), generator=g).int(), torch.randn(cap, generator=g) * 2
+    done = (torch.rand(cap, generator=g) < 0.2).float()
+    p = torch.rand(B, generator=g) + 0.05
+    st = H.new_step_state(DEV, 0.4, 100)
+    n_items = torch.tensor([cap], dtype=torch.int64, device=DEV)
+    # put a known total into the state through a real tree
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    allp = torch.rand(cap, generator=g) + 0.05
+    allp[idx.long()] = p
+    p = allp[idx.long()]
+    H.sumtree_ingest(tree, lay, 0, allp.to(DEV), None, torch.zeros(cap, dtype=torch.int32, device=DEV))
+    for _ in range(31):
+        H.step_end(st)                              # step = 31 -> beta = 0.4 + 0.6*31/100
+    H.step_begin(st, n_items)
+    H.sumtree_sample(tree, lay, st, 5, torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, device=DEV))
+    dq, newp = torch.zeros(B, A, device=DEV), torch.zeros(B, device=DEV)
+    delta, w = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    H.apex_td(q_on.to(DEV), q_tg.to(DEV), idx.to(DEV), act.to(DEV), rew.to(DEV), done.to(DEV), p.to(DEV), st, 0.97, 0.6, 1e-5,
+              dq, newp, delta, w)
+    beta = oracle.beta_schedule(31, 0.4, 100)
+    w_ref = oracle.is_weights(p, float(allp.double().sum()), cap, beta)
+    il = idx.long()
+    td = oracle.apex_td(q_on[:B], q_on[B:], q_tg, act[il], rew[il], done[il], w_ref, 0.97, 0.6)
+    torch.testing.assert_close(w.cpu(), w_ref, rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(delta.cpu(), td.delta, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(newp.cpu(), td.prio, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dq.cpu(), td.dq, rtol=2e-4, atol=1e-8)
+    s = H.read_step_state(st)
+    assert s["loss"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
+
+
+@pytest.mark.parametrize("done_offset", [0, 5])
+def test_r2d2_td(hip, done_offset):
+    H = hip
+    T, B, A, n, burn, cap = 120, 64, 6, 5, 40, 200
+    g = torch.Generator().manual_seed(7 + done_offset)
+    qo, qt = torch.randn(T, B, A, generator=g) * 3, torch.randn(T, B, A, generator=g) * 3
+    idx = torch.randint(0, cap, (B,), generator=g).int()
+    act = torch.randint(0, A, (cap, T), generator=g).int()
+    rew = torch.randn(cap, T, generator=g)
+    done = torch.zeros(cap, T)
+    lengths = torch.full((cap,), T, dtype=torch.int32)
+    short = torch.randperm(cap, generator=g)[:cap // 3]
+    lengths[short] = torch.randint(burn + 10, T, (len(short),), generator=g).int()
+    for s_ in short.tolist():
+        L = int(lengths[s_])
+        done[s_, L - n + 1:L] = 1.0
+        done[s_, L - 1] = 1.0
+    w = torch.rand(B, generator=g)
+    st = H.new_step_state(DEV, 0.6, 100)
+    dq, newp, sl = torch.full((T, B, A), 9.0, device=DEV), torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    st.zero_()
+    H.r2d2_td(qo.to(DEV), qt.to(DEV), idx.to(DEV), act.to(DEV), rew.to(DEV), done.to(DEV), lengths.to(DEV), w.to(DEV), st,
+              burn, n, done_offset, 0.985, 0.9, 1e-3, dq, newp, sl)
+    il = idx.long()
+    a_tb, r_tb, d_tb = act[il].t().long(), rew[il].t(), done[il].t()
+    mask = oracle.r2d2_learn_mask(lengths[il].long(), d_tb, T, burn, n, done_offset)
+    td = oracle.r2d2_td(qo, qt, a_tb, r_tb, d_tb, mask, w, 0.985, n, 0.9, 1e-3, done_offset)
+    torch.testing.assert_close(sl.cpu(), td.seq_loss, rtol=2e-4, atol=1e-5)
+    torch.testing.assert_close(newp.cpu(), td.prio, rtol=2e-4, atol=1e-5)
+    torch.testing.assert_close(dq.cpu(), td.dq, rtol=2e-3, atol=1e-5)
+    assert H.read_step_state(st)["loss"] == pytest.approx(float(td.loss), rel=5e-4)
+
+
+# ---- optimizer -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["rmsprop", "adam"])
+def test_fused_optimizer(hip, kind):
+    H = hip
+    n = 3_292_864
+    g_ = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g_)
+    p, m1, m2 = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    partial = torch.zeros(1024, device=DEV)
+    q, s1, s2 = p0.clone(), torch.zeros(n), torch.zeros(n)
+    st = H.new_step_state(DEV, 0.4, 100)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=g_) * (0.05 if step == 2 else 0.001)    # step 2 clips, others do not
+        gd = g.to(DEV)
+        npart = H.grad_sumsq(gd, partial)
+        if kind == "rmsprop":
+            H.rmsprop_step(p, gd, m1, pb, partial, npart, 0.5, 40.0, 6.25e-5, 0.95, 1.5e-7, st)
+        else:
+            H.adam_step(p, gd, m1, m2, pb, partial, npart, 0.5, 40.0, 1e-4, 0.9, 0.999, 1e-3, st)
+        H.step_end(st)
+        gs = g * 0.5                                                          # grad_scale = 1/world
+        coef = oracle.clip_coef(gs, 40.0)
+        if step == 2:
+            assert coef < 1.0
+        if kind == "rmsprop":
+            oracle.rmsprop_step(q, gs, s1, 6.25e-5, 0.95, 1.5e-7, coef)
+        else:
+            oracle.adam_step(q, gs, s1, s2, step, 1e-4, 0.9, 0.999, 1e-3, coef)
+        assert H.read_step_state(st)["grad_norm"] == pytest.approx(float(gs.norm()), rel=1e-4)
+        torch.testing.assert_close(p.cpu(), q, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pb.float().cpu(), q.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
+
+
+# ---- head ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,A,bias", [(1, 4, True), (50, 6, True), (513, 18, True), (256, 4, False)])
+def test_head_fwd_bwd(hip, M, A, bias):
+    H = hip
+    g = torch.Generator().manual_seed(M + A)
+    h = bf(torch.relu(torch.randn(M, 1024, generator=g)))
+    w_adv, w_val = bf(torch.randn(A, 512, generator=g) * 0.05), bf(torch.randn(1, 512, generator=g) * 0.05)
+    b_adv = torch.randn(A, generator=g) if bias else None
+    b_val = torch.randn(1, generator=g)
+    q = torch.zeros(M, A, device=DEV)
+    act = torch.zeros(M, dtype=torch.int32, device=DEV)
+    H.head_fwd(h.to(DEV), w_adv.to(DEV), b_adv.to(DEV) if bias else None, w_val.to(DEV), b_val.to(DEV), q, act)
+    hf = h.float().requires_grad_(True)
+    wa, wv = w_adv.float().requires_grad_(True), w_val.float().requires_grad_(True)
+    ba = b_adv.clone().requires_grad_(True) if bias else None
+    bv = b_val.clone().requires_grad_(True)
+    adv = hf[:, :512] @ wa.t() + (ba if bias else 0)
+    val = hf[:, 512:] @ wv.t() + bv
+    q_ref = oracle.dueling_combine(val, adv)
+    torch.testing.assert_close(q.cpu(), q_ref.detach(), rtol=1e-3, atol=1e-3)
+    assert (act.cpu().long() == q.cpu().argmax(1)).all()
+    dq = torch.randn(M, A, generator=g)
+    q_ref.backward(dq)
+    dh = torch.zeros(M, 1024, dtype=torch.bfloat16, device=DEV)
+    gwa, gwv = torch.zeros(A, 512, device=DEV), torch.zeros(1, 512, device=DEV)
+    gba, gbv = (torch.zeros(A, device=DEV) if bias else None), torch.zeros(1, device=DEV)
+    H.head_bwd(dq.to(DEV), h.to(DEV), w_adv.to(DEV), w_val.to(DEV), dh, gwa, gba, gwv, gbv)
+    dh_ref = hf.grad * (h.float() > 0)
+    torch.testing.assert_close(dh.float().cpu(), dh_ref, rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(gwa.cpu(), wa.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(gwv.cpu(), wv.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(gbv.cpu(), bv.grad, rtol=1e-3, atol=1e-3)
+    if bias:
+        torch.testing.assert_close(gba.cpu(), ba.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_head_eps_greedy(hip):
+    H = hip
+    M, A = 4096, 6
+    h = bf(torch.relu(torch.randn(M, 1024)))
+    w_adv, w_val = bf(torch.randn(A, 512) * 0.05), bf(torch.randn(1, 512) * 0.05)
+    q = torch.zeros(M, A, device=DEV)
+    act = torch.zeros(M, dtype=torch.int32, device=DEV)
+    eps = torch.tensor([0.0, 1.0, 0.5, 0.25], device=DEV)
+    ctr = torch.tensor([3], dtype=torch.int64, device=DEV)
+    H.head_fwd(h.to(DEV), w_adv.to(DEV), torch.zeros(A, device=DEV), w_val.to(DEV), torch.zeros(1, device=DEV), q, act, eps, 4, 99, ctr)
+    greedy = q.argmax(1).cpu()
+    a = act.cpu().long()
+    rows = torch.arange(M)
+    assert (a[rows % 4 == 0] == greedy[rows % 4 == 0]).all()                     # eps 0: always greedy
+    r1 = a[rows % 4 == 1]
+    assert np.bincount(r1.numpy(), minlength=A).min() > 0.6 * len(r1) / A        # eps 1: uniform over actions
+    frac = (a[rows % 4 == 2] != greedy[rows % 4 == 2]).float().mean().item()
+    assert abs(frac - 0.5 * (A - 1) / A) < 0.06
+    act2 = torch.zeros_like(act)
+    H.head_fwd(h.to(DEV), w_adv.to(DEV), torch.zeros(A, device=DEV), w_val.to(DEV), torch.zeros(1, device=DEV), q, act2, eps, 4, 99, ctr)
+    assert torch.equal(act, act2)                                                # counter-based RNG: reproducible
+
+
+# ---- GEMM ----------------------------------------------------------------------------------------------
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("M,N,K,big", [(64, 64, 64, False), (100, 128, 192, False), (512, 1024, 3136, False),
+                                       (1000, 3136, 1024, False), (2500, 2048, 512, True), (130, 256, 128, True)])
+def test_gemm_nt_bias_relu(hip, M, N, K, big):
+    H = hip
+    a, w = _rnd(M, K, seed=1), _rnd(N, K, seed=2, scale=0.05)
+    bias = torch.randn(N)
+    c = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm(H.NT, a.to(DEV), w.to(DEV), c, M, N, K, bias=bias.to(DEV), flags=H.EPI_RELU, big=big)
+    ref = torch.relu(a.float() @ w.float().t() + bias)
+    torch.testing.assert_close(c.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    c32 = torch.zeros(M, N, device=DEV)
+    H.gemm(H.NT, a.to(DEV), w.to(DEV), c32, M, N, K, bias=bias.to(DEV), flags=H.EPI_OUT_F32, big=big)
+    torch.testing.assert_close(c32.cpu(), a.float() @ w.float().t() + bias, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,big", [(64, 64, 64, False), (512, 3136, 1024, False), (777, 576, 64, False), (300, 256, 128, True)])
+def test_gemm_nn_mask(hip, M, N, K, big):
+    H = hip
+    a, b = _rnd(M, K, seed=3), _rnd(K, N, seed=4, scale=0.05)          # asymmetric operands (guide §3: A=I checks)
+    mask = _rnd(M, N, seed=5)
+    c = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm(H.NN, a.to(DEV), b.to(DEV), c, M, N, K, mask=mask.to(DEV), flags=H.EPI_MASK, big=big)
+    ref = (a.float() @ b.float()) * (mask.float() > 0)
+    torch.testing.assert_close(c.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    eye = bf(torch.eye(64))
+    b2 = _rnd(64, 64, seed=6)
+    c2 = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    H.gemm(H.NN, eye.to(DEV), b2.to(DEV), c2, 64, 64, 64, big=False)
+    assert torch.equal(c2.cpu(), b2)
+
+
+@pytest.mark.parametrize("M,N,K,big,splits", [(64, 64, 64, False, 1), (1024, 3136, 512, False, 1), (64, 576, 25088, False, 28),
+                                              (128, 256, 1000, True, 1), (64, 128, 4807, False, 5)])
+def test_gemm_tn_splitk(hip, M, N, K, big, splits):
+    H = hip
+    a, b = _rnd(K, M, seed=7, scale=0.1), _rnd(K, N, seed=8, scale=0.1)
+    c = torch.zeros(M, N, device=DEV)
+    flags = H.EPI_OUT_F32 | (H.EPI_ATOMIC if splits > 1 else 0)
+    H.gemm(H.TN, a.to(DEV), b.to(DEV), c, M, N, K, flags=flags, splits=splits, big=big)
+    ref = a.float().t() @ b.float()
+    torch.testing.assert_close(c.cpu(), ref, rtol=2e-3, atol=2e-3 * (K ** 0.5) * 0.01 + 1e-3)
+
+
+# ---- conv ----------------------------------------------------------------------------------------------
+LAYERS = {1: (4, 32, 8, 4, 84), 2: (32, 64, 4, 2, 20), 3: (64, 64, 3, 1, 9)}
+
+
+def _conv_setup(layer, frames, seed):
+    cin, cout, ks, s, hw = LAYERS[layer]
+    g = torch.Generator().manual_seed(seed)
+    if layer == 1:
+        x = torch.randint(0, 256, (frames, hw, hw, cin), dtype=torch.uint8, generator=g)
+        xf = x.float() / 255
+    else:
+        x = bf(torch.relu(torch.randn(frames, hw, hw, cin, generator=g)))
+        xf = x.float()
+    w = bf(torch.randn(cout, ks, ks, cin, generator=g) * (1.0 / (ks * ks * cin) ** 0.5))
+    bias = torch.randn(cout, generator=g) * 0.1
+    return x, xf, w, bias, (cin, cout, ks, s, hw)
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("frames", [1, 7, 96])
+def test_conv_fwd(hip, layer, frames):
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 100 + frames)
+    oh = (hw - ks) // s + 1
+    out = torch.zeros(frames, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
+    H.conv_fwd(layer, x.to(DEV), w.to(DEV), bias.to(DEV), out, frames)
+    ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=s)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_conv1_frame_offsets(hip):
+    H = hip
+    store = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    pick = torch.tensor([7, 3, 19, 7, 0])
+    _, _, w, bias, _ = _conv_setup(1, 1, 5)
+    out = torch.zeros(5, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    H.conv_fwd(1, store.to(DEV), w.to(DEV), bias.to(DEV), out, 5, frame_off=(pick * 28224).to(DEV))
+    ref = torch.zeros_like(out)
+    H.conv_fwd(1, store[pick].contiguous().to(DEV), w.to(DEV), bias.to(DEV), ref, 5)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("frames,splits", [(3, 1), (64, 16)])
+def test_conv_wgrad_and_bias(hip, layer, frames, splits):
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 7 + frames)
+    oh = (hw - ks) // s + 1
+    g = torch.Generator().manual_seed(11)
+    dy = bf(torch.randn(frames, oh, oh, cout, generator=g) * 0.1)
+    wf = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    bf_ = bias.clone().requires_grad_(True)
+    y = F.conv2d(xf.permute(0, 3, 1, 2), wf, bf_, stride=s)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    dw = torch.zeros(cout, ks, ks, cin, device=DEV)
+    H.conv_wgrad(layer, x.to(DEV), dy.to(DEV), dw, frames, splits=splits)
+    ref = wf.grad.permute(0, 2, 3, 1)
+    torch.testing.assert_close(dw.cpu(), ref, rtol=5e-3, atol=5e-3 * float(ref.abs().max()))
+    db = torch.zeros(cout, device=DEV)
+    H.colsum(dy.to(DEV), db, frames * oh * oh, cout)
+    torch.testing.assert_close(db.cpu(), bf_.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("frames", [2, 33])
+def test_conv_dgrad(hip, layer, frames):
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 13 + frames)
+    oh = (hw - ks) // s + 1
+    g = torch.Generator().manual_seed(12)
+    dy = bf(torch.randn(frames, oh, oh, cout, generator=g) * 0.1)
+    xin = xf.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    F.conv2d(xin, w.float().permute(0, 3, 1, 2), None, stride=s).backward(dy.float().permute(0, 3, 1, 2))
+    dcol = torch.zeros(frames * oh * oh, ks * ks * cin, dtype=torch.bfloat16, device=DEV)
+    H.conv_dcol(layer, dy.to(DEV), w.to(DEV), dcol, frames)
+    dx = torch.zeros(frames, hw, hw, cin, dtype=torch.bfloat16, device=DEV)
+    H.col2im(layer, dcol, x.to(DEV), dx, frames)
+    ref = xin.grad.permute(0, 2, 3, 1) * (xf > 0)
+    torch.testing.assert_close(dx.float().cpu(), ref, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
