@@ -1,0 +1,120 @@
+"""ActorEngine — batched ε-greedy inference for E environments on one MI355X.
+
+The reference runs one env per process and one B=1 forward per env step (ape_x/actor.py:70, utils.py:36-41). Here
+one process feeds E environments through ONE torso → FC1 → head launch chain (5 kernels, captured as a hipGraph);
+the head kernel also draws the ε-greedy action on device (per-env ε from the reference's ladder, Philox RNG), so
+what returns to the host per step is E int32 actions.
+
+Parameters are either *shared* with a learner engine on the same GPU (the actor reads the learner's live bf16
+weights — the "param sync" is free) or owned and refreshed from a flat fp32 buffer (ParamChannel pull or RCCL
+broadcast, parallel/dist.py).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ..models import DuelingDQN
+from ..models.packing import ParamPack, apex_layout
+from ..ops import hip as H
+from ..utils import epsilon_ladder
+from .apex import TorsoBuffers, torso_forward
+
+
+class ActorEngine:
+    def __init__(self, n_action: int, num_envs: int, device="cuda", params=None, eps: Optional[np.ndarray] = None,
+                 seed: int = 0, use_graph: bool = True, init_model: Optional[DuelingDQN] = None):
+        self.A, self.E = n_action, num_envs
+        self.device = dev = torch.device(device)
+        if params is not None:                      # share the learner's buffers (same GPU)
+            self.P, self.Pb = params.P, params.Pb
+            self.owns = False
+        else:
+            model = init_model if init_model is not None else DuelingDQN(n_action)
+            self.P = ParamPack(apex_layout(n_action), dev)
+            self.P.load_state_dict(model.state_dict())
+            self.Pb = self.P.like(torch.bfloat16)
+            H.cast_bf16(self.P.flat, self.Pb.flat)
+            self.owns = True
+        self.buf = TorsoBuffers(num_envs, n_action, dev)
+        self.obs = torch.zeros(num_envs, 84, 84, 4, dtype=torch.uint8, device=dev)
+        self.action = torch.zeros(num_envs, dtype=torch.int32, device=dev)
+        e = eps if eps is not None else epsilon_ladder(num_envs)
+        self.eps = torch.as_tensor(e, dtype=torch.float32, device=dev).contiguous()
+        self.seed = seed
+        self.st = H.new_step_state(dev, 1.0, 1)      # only its rng_ctr is used
+        self._n = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._ctr = self.st[8:16]
+        self.use_graph = use_graph
+        self._graph = None
+        self._host_obs = None
+        self._host_act = None
+        self._pool = None
+        self._k = 0
+
+    # ---- parameters -----------------------------------------------------------------------------------
+    def load_flat(self, flat_fp32) -> None:
+        """Refresh from a flat fp32 parameter buffer in kernel layout (ParamChannel.pull / broadcast target)."""
+        assert self.owns, "shared-parameter actors read the learner's weights directly"
+        t = torch.as_tensor(flat_fp32)
+        self.P.flat.copy_(t.to(self.device, non_blocking=True))
+        H.cast_bf16(self.P.flat, self.Pb.flat)
+
+    # ---- inference --------------------------------------------------------------------------------------
+    def _launch(self) -> None:
+        H.step_begin(self.st, self._n)               # advances the Philox counter on device
+        torso_forward(self.obs, None, self.E, self.Pb, self.P, self.buf, self.action, self.eps, 0, self.seed, self._ctr)
+
+    def infer(self) -> torch.Tensor:
+        """Q + ε-greedy actions for the frames currently in ``self.obs``; returns the device action tensor."""
+        if not self.use_graph:
+            self._launch()
+            return self.action
+        if self._graph is None:
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._launch()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._launch()
+        self._graph.replay()
+        return self.action
+
+    def act(self, obs_u8: np.ndarray) -> np.ndarray:
+        """Host frames (E,84,84,4) uint8 → host actions: pinned H2D, graph replay, pinned D2H."""
+        if self._host_obs is None:
+            self._host_obs = torch.zeros(self.E, 84, 84, 4, dtype=torch.uint8).pin_memory()
+            self._host_act = torch.zeros(self.E, dtype=torch.int32).pin_memory()
+        self._host_obs.numpy()[...] = obs_u8
+        self.obs.copy_(self._host_obs, non_blocking=True)
+        self.infer()
+        self._host_act.copy_(self.action, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._host_act.numpy().astype(np.int64)
+
+    def q_values(self) -> torch.Tensor:
+        return self.buf.q
+
+    # ---- benchmarks -------------------------------------------------------------------------------------
+    def step_synthetic(self) -> None:
+        """One inference step on device-resident random frames (pure GPU path)."""
+        if self._pool is None:
+            self._pool = torch.randint(0, 256, (2, self.E, 84, 84, 4), dtype=torch.uint8, device=self.device)
+        self.obs.copy_(self._pool[self._k & 1])
+        self._k += 1
+        self.infer()
+
+    def step_host(self) -> None:
+        """One inference step including the PCIe round trip (pinned uint8 frames in, int32 actions out)."""
+        if self._host_obs is None:
+            self._host_obs = torch.randint(0, 256, (self.E, 84, 84, 4), dtype=torch.uint8).pin_memory()
+            self._host_act = torch.zeros(self.E, dtype=torch.int32).pin_memory()
+        self.obs.copy_(self._host_obs, non_blocking=True)
+        self.infer()
+        self._host_act.copy_(self.action, non_blocking=True)
+        torch.cuda.current_stream().synchronize()

@@ -1,0 +1,202 @@
+"""ApexEngine — the graph-captured gfx950 Ape-X learner step (replaces the hot loop of ape_x/learner.py:63-99).
+
+One step = one hipGraph replay (``torch.cuda.CUDAGraph``) of hand-written kernels; nothing returns to the host
+between PER sampling and the priority write-back:
+
+  step_begin → sum-tree sample (idx, prio, gen, frame byte offsets)
+  online  torso on [s ; s'] (2B frames, conv1 reads uint8 straight from the replay store) → FC1 → head → Q
+  target  torso on s' → Q_target
+  fused TD (IS weights, double-DQN target, Huber, loss, dL/dQ, new priorities)
+  backward: head → FC1 (dW, db, dX·ReLU') → conv3/2/1 (wgrad split-K, bias colsum, dCol GEMM + col2im·ReLU')
+  [RCCL all-reduce of the flat gradient buffer when world_size > 1]
+  global-norm clip + RMSprop + bf16 re-cast (2 launches over the flat buffers)
+  sum-tree priority write-back → step_end → (every target_update steps) target ← online (one flat copy)
+
+Parameters, gradients and optimizer state are flat fp32 buffers in kernel layout (models/packing.py); the MFMA
+kernels read a bf16 shadow that the optimizer kernel refreshes. Checkpoints go through ``state_dict()`` in the
+reference's format.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..config import ApexConfig
+from ..models import DuelingDQN
+from ..models.packing import ParamPack, apex_layout
+from ..ops import hip as H
+from ..replay.device_per import DevicePER
+
+
+class TorsoBuffers:
+    """Activations of the Nature-CNN torso + FC1 + head for ``n`` frames (NHWC bf16)."""
+
+    def __init__(self, n: int, n_action: int, device):
+        bf = dict(dtype=torch.bfloat16, device=device)
+        self.n = n
+        self.act1 = torch.zeros(n, 20, 20, 32, **bf)
+        self.act2 = torch.zeros(n, 9, 9, 64, **bf)
+        self.act3 = torch.zeros(n, 3136, **bf)
+        self.h = torch.zeros(n, 1024, **bf)
+        self.q = torch.zeros(n, n_action, device=device)
+
+
+def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int, wb: ParamPack, wf: ParamPack,
+                  buf: TorsoBuffers, action_out=None, eps=None, eps_mod: int = 0, seed: int = 0, ctr=None) -> None:
+    """wb = bf16 weights, wf = fp32 params (biases). 5 launches: conv1-3, FC1(+bias+ReLU), head(+dueling[+ε-greedy])."""
+    H.conv_fwd(1, x_u8, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
+    H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, n)
+    H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, n)
+    H.gemm(H.NT, buf.act3, wb.view("fc1.w"), buf.h, n, 1024, 3136, bias=wf.view("fc1.b"), flags=H.EPI_RELU)
+    H.head_fwd(buf.h, wb.view("adv2.w"), wf.view("adv2.b"), wb.view("val2.w"), wf.view("val2.b"), buf.q, action_out,
+               eps, eps_mod, seed, ctr)
+
+
+class ApexEngine:
+    def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
+                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 96):
+        self.cfg, self.replay, self.dist = cfg, replay, dist
+        self.device = torch.device(device)
+        self.A = n_action
+        self.B = B = cfg.batch_size
+        assert replay.batch_size == B
+        dev = self.device
+        model = init_model if init_model is not None else DuelingDQN(n_action)
+        lay = apex_layout(n_action)
+        self.P = ParamPack(lay, dev)                    # fp32 master (online)
+        self.P.load_state_dict(model.state_dict())
+        self.Pb = self.P.like(torch.bfloat16)           # bf16 shadow read by the MFMA kernels
+        self.T = self.P.like()                          # target fp32 (biases) ...
+        self.Tb = self.P.like(torch.bfloat16)           # ... and bf16
+        self.G = self.P.like()                          # flat gradient
+        self.SQ = self.P.like()                         # RMSprop second moment
+        H.cast_bf16(self.P.flat, self.Pb.flat)
+        self.sync_target()
+        self.st = H.new_step_state(dev, cfg.beta0, cfg.beta_decay)
+        self.partial = torch.zeros(1024, device=dev)
+        self.n_partial = H.n_partials(self.P.flat.numel())
+        self.on = TorsoBuffers(2 * B, n_action, dev)
+        self.tg = TorsoBuffers(B, n_action, dev)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self.dq = torch.zeros(B, n_action, device=dev)
+        self.new_prio = torch.zeros(B, device=dev)
+        self.dh = torch.zeros(B, 1024, **bf)
+        self.d3 = torch.zeros(B * 49, 64, **bf)          # d conv3 pre-activation
+        self.dcol3 = torch.zeros(B * 49, 576, **bf)
+        self.d2 = torch.zeros(B * 81, 64, **bf)          # d conv2 pre-activation
+        self.dcol2 = torch.zeros(B * 81, 512, **bf)
+        self.d1 = torch.zeros(B * 400, 32, **bf)         # d conv1 pre-activation
+        self.wgrad_splits = wgrad_splits
+        self.world = dist.world_size if dist is not None else 1
+        self.use_graph = use_graph
+        self._graphs = None
+        self.steps_done = 0
+
+    # ---- pieces -------------------------------------------------------------------------------------
+    def sync_target(self) -> None:
+        self.T.flat.copy_(self.P.flat)
+        self.Tb.flat.copy_(self.Pb.flat)
+
+    def _forward_backward(self) -> None:
+        B, A, r, cfg = self.B, self.A, self.replay, self.cfg
+        H.step_begin(self.st, r.n_items)
+        r.sample(self.st)
+        self.G.flat.zero_()
+        torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
+        torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
+        H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
+                  cfg.prio_eps, self.dq, self.new_prio, n_scale=1.0)
+        G, Pb, on = self.G, self.Pb, self.on
+        h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
+        H.head_bwd(self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
+                   G.view("val2.w"), G.view("val2.b"))
+        H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
+        H.colsum(self.dh, G.view("fc1.b"), B, 1024)
+        H.gemm(H.NN, self.dh, Pb.view("fc1.w"), self.d3.view(B, 3136), B, 3136, 1024, mask=a3, flags=H.EPI_MASK, big=False)
+        sp = self.wgrad_splits
+        H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
+        H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
+        H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, B)
+        H.col2im(3, self.dcol3, a2, self.d2, B)
+        H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), B, splits=sp)
+        H.colsum(self.d2, G.view("conv2.b"), B * 81, 64)
+        H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, B)
+        H.col2im(2, self.dcol2, a1, self.d1, B)
+        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), B, frame_off=r.frame_off, splits=2 * sp)
+        H.colsum(self.d1, G.view("conv1.b"), B * 400, 32)
+
+    def _optimize(self) -> None:
+        cfg = self.cfg
+        H.grad_sumsq(self.G.flat, self.partial)
+        H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
+                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st)
+        self.replay.update(self.new_prio)
+        H.step_end(self.st)
+
+    def _all_reduce(self) -> None:
+        if self.world > 1:
+            self.dist.all_reduce_flat(self.G.flat)
+
+    # ---- step ---------------------------------------------------------------------------------------
+    def _eager_step(self) -> None:
+        self._forward_backward()
+        self._all_reduce()
+        self._optimize()
+
+    def capture(self) -> None:
+        """Warm up eagerly, then capture. world==1: one graph. world>1: try one graph including the RCCL
+        all-reduce; if the collective cannot be captured fall back to graph / eager all-reduce / graph."""
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_step()
+            self._graphs = ("one", g)
+        except Exception:
+            if self.world == 1:
+                raise
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._forward_backward()
+            with torch.cuda.graph(g2):
+                self._optimize()
+            self._graphs = ("split", g1, g2)
+        self.steps_done += 2
+
+    def step(self) -> None:
+        if self.use_graph:
+            if self._graphs is None:
+                self.capture()
+            if self._graphs[0] == "one":
+                self._graphs[1].replay()
+            else:
+                self._graphs[1].replay()
+                self._all_reduce()
+                self._graphs[2].replay()
+        else:
+            self._eager_step()
+        self.steps_done += 1
+        if self.steps_done % self.cfg.target_update == 0:
+            self.sync_target()
+
+    # ---- host-visible state ---------------------------------------------------------------------------
+    def stats(self) -> dict:
+        return H.read_step_state(self.st)
+
+    def state_dict(self):
+        return self.P.state_dict()
+
+    def load_state_dict(self, sd) -> None:
+        self.P.load_state_dict(sd)
+        H.cast_bf16(self.P.flat, self.Pb.flat)
+
+    def flat_params(self) -> torch.Tensor:
+        return self.P.flat

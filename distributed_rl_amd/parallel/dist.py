@@ -1,0 +1,93 @@
+"""Process-group glue: one process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm),
+"gloo" on CPU for tests.
+
+Design for xGMI (point-to-point links, latency-bound 13-32 MB payloads):
+
+* **one flat bucket** — all gradients are contiguous in one buffer (models/packing.py), so a step issues exactly
+  ONE all-reduce (sum); the 1/world averaging is folded into the fused optimizer kernel's ``grad_scale``.
+  No per-tensor buckets, no DDP hooks.
+* **param broadcast** of the flat fp32/bf16 parameter buffer from the learner rank to actor GPUs, versioned by a
+  step counter (replaces ``SET/GET params``, ape_x/learner.py:83, ape_x/actor.py:52-56).
+* **sharded PER**: every rank owns a replay shard in its own HBM and samples locally; the scalars needed for
+  single-tree-equivalent IS weights (Σp, N, max w) travel in one tiny all-reduce / all-gather (M8).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as td
+
+
+class Dist:
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: int = 600):
+        import datetime
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if device is None:
+            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+        self.backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        self.enabled = self.world_size > 1
+        if self.enabled and not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            kw = {}
+            if self.backend == "nccl":
+                kw["device_id"] = device
+            td.init_process_group(self.backend, rank=self.rank, world_size=self.world_size,
+                                  timeout=datetime.timedelta(seconds=timeout_s), **kw)
+
+    # ---- collectives --------------------------------------------------------------------------------
+    def all_reduce_flat(self, flat: torch.Tensor) -> None:
+        """SUM over ranks, in place, one collective for the whole gradient."""
+        if self.enabled:
+            td.all_reduce(flat, op=td.ReduceOp.SUM)
+
+    def all_reduce_grads(self, module: torch.nn.Module) -> None:
+        """PyTorch-learner path: flatten → one all-reduce → average → scatter back."""
+        if not self.enabled:
+            return
+        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        flat.div_(self.world_size)
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view_as(g))
+            o += n
+
+    def broadcast_flat(self, flat: torch.Tensor, src: int = 0) -> None:
+        if self.enabled:
+            td.broadcast(flat, src=src)
+
+    def shard_scalars(self, total_prio: float, n_items: int) -> tuple:
+        """→ (Σp over all shards, N over all shards)."""
+        if not self.enabled:
+            return total_prio, n_items
+        t = torch.tensor([total_prio, float(n_items)], dtype=torch.float64, device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return float(t[0]), int(t[1])
+
+    def max_scalar(self, x: float) -> float:
+        if not self.enabled:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t[0])
+
+    def barrier(self) -> None:
+        if self.enabled:
+            if self.backend == "nccl":
+                td.barrier(device_ids=[self.device.index])
+            else:
+                td.barrier()
+
+    def close(self) -> None:
+        if self.enabled and td.is_initialized():
+            td.destroy_process_group()

@@ -1,0 +1,132 @@
+"""HBM-resident prioritized replay for transitions (replaces PrioritizedMemory + Replay thread,
+libs/replay_memory.py:51-81, ape_x/replay.py).
+
+Everything lives in device memory, sized for the 288 GB of an MI355X:
+
+* ``frames``  uint8 ``[2·cap, 84·84·4]`` — states in the first half, next-states in the second (2 M transitions =
+  113 GB; the reference's float32 pickles would need 452 GB). HWC layout, so conv1's implicit-GEMM
+  reads 32 contiguous bytes per kernel row straight out of this store through the sampled byte offsets — a
+  sampled batch is never gathered or copied.
+* ``act / rew / done`` per slot, ``gen`` per-slot generation, and the 64-ary sum-tree.
+
+It is a ring: ingest overwrites the oldest slots (FIFO, like ``remove_to_fit`` — replay_memory.py:70-75 — but
+immediate instead of every 100 steps: documented deviation). ``sample`` and ``update`` are pure
+kernel launches on the current stream with preallocated outputs, so they can sit inside a captured hipGraph;
+the number of live items is a device scalar for the same reason.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from ..ops import hip as H
+
+FRAME_BYTES = 84 * 84 * 4
+
+
+class DevicePER:
+    def __init__(self, capacity: int, device="cuda", batch_size: int = 512, seed: int = 0,
+                 frame_bytes: int = FRAME_BYTES, max_ingest: int = 4096):
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        self.frame_bytes = frame_bytes
+        self.batch_size = batch_size
+        self.seed = seed
+        self.lay = H.TreeLayout(self.capacity)
+        dev = self.device
+        self.tree = torch.zeros(self.lay.total, device=dev)
+        self.gen = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
+        self.frames = torch.zeros(2 * self.capacity, frame_bytes, dtype=torch.uint8, device=dev)
+        self.act = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
+        self.rew = torch.zeros(self.capacity, device=dev)
+        self.done = torch.zeros(self.capacity, device=dev)
+        self.n_items = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._scratch = torch.zeros(max(max_ingest, 64), dtype=torch.int32, device=dev)
+        self.cursor = 0
+        self.count = 0
+        # sample outputs (fixed addresses: graph-capturable)
+        B = batch_size
+        self.idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.prio = torch.zeros(B, device=dev)
+        self.gen_s = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.frame_off = torch.zeros(2 * B, dtype=torch.int64, device=dev)
+
+    def __len__(self) -> int:
+        return self.count
+
+    def total_prios(self) -> float:
+        top = self.lay.offsets[-1]
+        return float(self.tree[top:top + 64].sum())
+
+    # ---- ingest -----------------------------------------------------------------------------------
+    def _ring_write(self, dst: torch.Tensor, src: torch.Tensor, start: int) -> None:
+        n = src.shape[0]
+        first = min(n, self.capacity - start)
+        dst[start:start + first].copy_(src[:first], non_blocking=True)
+        if first < n:
+            dst[:n - first].copy_(src[first:], non_blocking=True)
+
+    def ingest(self, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor, reward: torch.Tensor,
+               done: torch.Tensor, prio: torch.Tensor) -> int:
+        """Append K transitions (tensors on any device; frames uint8 HWC, flattened or not)."""
+        K = int(action.shape[0])
+        if K == 0:
+            return 0
+        if K > self.capacity:
+            raise ValueError("block larger than the replay")
+        if K > self._scratch.numel():
+            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
+        dev = self.device
+        s = self.cursor
+        self._ring_write(self.frames[:self.capacity], state.reshape(K, -1).to(dev, non_blocking=True), s)
+        self._ring_write(self.frames[self.capacity:], next_state.reshape(K, -1).to(dev, non_blocking=True), s)
+        self._ring_write(self.act, action.to(dev, torch.int32, non_blocking=True), s)
+        self._ring_write(self.rew, reward.to(dev, torch.float32, non_blocking=True), s)
+        self._ring_write(self.done, done.to(dev, torch.float32, non_blocking=True), s)
+        H.sumtree_ingest(self.tree, self.lay, s, prio.to(dev, torch.float32).contiguous(), self.gen, self._scratch)
+        self.cursor = (s + K) % self.capacity
+        self.count = min(self.capacity, self.count + K)
+        self.n_items.fill_(self.count)
+        return K
+
+    def ingest_block(self, block: Dict[str, np.ndarray]) -> int:
+        """Consume a decoded experience block (transport/codec.py KIND_APEX)."""
+        t = torch.from_numpy
+        return self.ingest(t(np.ascontiguousarray(block["state"])), t(np.ascontiguousarray(block["next_state"])),
+                           t(np.ascontiguousarray(block["action"])), t(np.ascontiguousarray(block["reward"])),
+                           t(np.ascontiguousarray(block["done"])), t(np.ascontiguousarray(block["prio"])))
+
+    def fill_synthetic(self, n: Optional[int] = None, n_action: int = 4, chunk: int = 65536, seed: int = 0) -> None:
+        """Fill with random Atari-shaped transitions generated ON DEVICE (benchmarks: no dataset, no H2D)."""
+        n = self.capacity if n is None else n
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        done = 0
+        while done < n:
+            k = min(chunk, n - done)
+            fr = torch.randint(0, 256, (2, k, self.frame_bytes), dtype=torch.uint8, device=self.device, generator=g)
+            self.ingest(fr[0], fr[1], torch.randint(0, n_action, (k,), device=self.device, generator=g),
+                        torch.randn(k, device=self.device, generator=g).clamp_(-1, 1),
+                        (torch.rand(k, device=self.device, generator=g) < 0.01).float(),
+                        torch.rand(k, device=self.device, generator=g) + 0.1)
+            done += k
+
+    # ---- sample / update (graph-capturable) -----------------------------------------------------
+    def sample(self, st: torch.Tensor) -> None:
+        """Draw ``batch_size`` slots ∝ priority into ``self.idx / prio / gen_s / frame_off``."""
+        H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
+                         self.frame_bytes)
+
+    def update(self, new_prio: torch.Tensor) -> None:
+        """Write back priorities of the last sample; slots overwritten since are skipped (generation check)."""
+        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s)
+
+    # host-API parity with PrioritizedMemory (tests / tools; not on the hot path)
+    def update_priorities(self, indices, priorities) -> None:
+        idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device)
+        val = torch.as_tensor(priorities, dtype=torch.float32, device=self.device)
+        H.sumtree_update(self.tree, self.lay, idx.contiguous(), val.contiguous())
+
+    def remove_to_fit(self) -> int:
+        return 0     # the ring evicts on ingest

@@ -1,0 +1,120 @@
+"""ApexEngine (hand-written gfx950 learner step) against the PyTorch fp32 oracle on the same sampled batch:
+Q values, loss, priorities, every gradient tensor, the clipped RMSprop update, graph replay == eager."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from distributed_rl_amd.config import ApexConfig  # noqa: E402
+from distributed_rl_amd.models import DuelingDQN  # noqa: E402
+from distributed_rl_amd.ops import oracle  # noqa: E402
+
+
+def _setup(B=64, cap=1000, A=6, seed=0):
+    from distributed_rl_amd.engine.apex import ApexEngine
+    from distributed_rl_amd.replay.device_per import DevicePER
+    torch.manual_seed(seed)
+    model = DuelingDQN(A)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())           # weights exactly representable in bf16
+    cfg = ApexConfig(batch_size=B, target_update=10 ** 9)
+    rep = DevicePER(cap, "cuda", batch_size=B, seed=3)
+    rep.fill_synthetic(cap - 100, n_action=A, seed=1)
+    eng = ApexEngine(A, cfg, rep, "cuda", init_model=model, use_graph=False)
+    return model, cfg, rep, eng
+
+
+def _reference(model, target, cfg, rep, eng):
+    B = cfg.batch_size
+    idx = rep.idx.long()
+    s = rep.frames[:rep.capacity][idx].view(B, 84, 84, 4).cpu()
+    s2 = rep.frames[rep.capacity:][idx].view(B, 84, 84, 4).cpu()
+    a, r, d = rep.act[idx].cpu().long(), rep.rew[idx].cpu(), rep.done[idx].cpu()
+    st = eng.stats()
+    w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"])
+    model.zero_grad()
+    td = model.td_batch(target, s, a, r, s2, d, w, cfg.per_alpha, cfg.gamma_n)
+    td.loss.backward()
+    return td, (s, s2)
+
+
+def test_apex_engine_step_matches_oracle():
+    model, cfg, rep, eng = _setup()
+    target = DuelingDQN(eng.A)
+    target.load_state_dict(model.state_dict())
+    eng._forward_backward()
+    torch.cuda.synchronize()
+    td, (s, s2) = _reference(model, target, cfg, rep, eng)
+    B = cfg.batch_size
+    with torch.no_grad():
+        q_ref = model(torch.cat([s, s2]))
+    torch.testing.assert_close(eng.on.q.cpu(), q_ref, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(eng.tg.q.cpu(), q_ref[B:], rtol=3e-2, atol=3e-2)
+    assert eng.stats()["loss"] == pytest.approx(float(td.loss), rel=5e-2, abs=2e-3)
+    torch.testing.assert_close(eng.new_prio.cpu(), td.prio, rtol=1e-1, atol=2e-2)
+    grads = eng.G.state_dict()
+    errs = {}
+    for name, p in model.named_parameters():
+        g, ref = grads[name], p.grad
+        errs[name] = (float((g - ref).norm() / (ref.norm() + 1e-12)), float(ref.norm()), float(g.norm()))
+    print(errs)
+    assert all(e[0] < 6e-2 for e in errs.values()), errs
+    # optimizer: same gradients through torch RMSprop + clip
+    opt = torch.optim.RMSprop(model.parameters(), lr=cfg.lr, alpha=cfg.rms_alpha, eps=cfg.rms_eps)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.grad.copy_(grads[name])
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
+    opt.step()
+    eng._optimize()
+    torch.cuda.synchronize()
+    assert eng.stats()["grad_norm"] == pytest.approx(float(gn), rel=1e-3)
+    new = eng.state_dict()
+    for name, p in model.named_parameters():
+        torch.testing.assert_close(new[name], p.detach(), rtol=1e-4, atol=1e-6)
+    # priorities were written back into the tree at the sampled slots
+    leaves = rep.tree[:rep.capacity][rep.idx.long()].cpu()
+    torch.testing.assert_close(leaves, eng.new_prio.cpu())
+    assert eng.stats()["step"] == 1
+
+
+def test_apex_engine_graph_equals_eager_and_learns():
+    _, cfg, rep, e1 = _setup(seed=1)
+    _, _, rep2, e2 = _setup(seed=1)
+    e2.use_graph = True
+    for _ in range(7):
+        e1.step()
+    for _ in range(5):
+        e2.step()                     # 2 eager warm-up steps inside capture + 5 graph replays
+    torch.cuda.synchronize()
+    assert e2._graphs[0] == "one"
+    assert e1.stats()["step"] == 7 and e2.stats()["step"] == 7
+    a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
+    assert torch.isfinite(a).all()
+    assert (a - b).norm() / a.norm() < 1e-3          # same RNG stream, same data; atomics reorder only
+    # loss goes down on a fixed tiny replay
+    first = None
+    for i in range(150):
+        e2.step()
+        if i == 0:
+            first = e2.stats()["loss"]
+    assert e2.stats()["loss"] < first
+
+
+def test_device_per_block_ingest_roundtrip():
+    import numpy as np
+    from distributed_rl_amd.replay.device_per import DevicePER
+    rep = DevicePER(64, "cuda", batch_size=8)
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        blk = dict(state=rng.integers(0, 256, (30, 84, 84, 4), dtype=np.uint8), next_state=rng.integers(0, 256, (30, 84, 84, 4), dtype=np.uint8),
+                   action=rng.integers(0, 4, 30).astype(np.int32), reward=rng.random(30).astype(np.float32),
+                   done=np.zeros(30, np.float32), prio=(rng.random(30) + 0.1).astype(np.float32))
+        rep.ingest_block(blk)
+    assert len(rep) == 64 and rep.cursor == 90 % 64
+    # last block occupies slots 60..63,0..25
+    assert np.array_equal(rep.frames[60].cpu().numpy(), blk["state"][0].reshape(-1))
+    assert np.array_equal(rep.frames[64 + 25].cpu().numpy(), blk["next_state"][29].reshape(-1))
+    assert rep.total_prios() == pytest.approx(float(rep.tree[:64].sum()), rel=1e-6)
+    assert int(rep.gen[0]) == 2 and int(rep.gen[59]) == 1
