@@ -52,13 +52,14 @@ __global__ __launch_bounds__(256) void k_col2im(const bf16_t* __restrict__ dcol,
     }
 }
 
-// db[n] += sum_m dY[m][n]; grid = (N/CW, ceil(M/1024)), block = 256 (256/CW row phases x CW columns)
+// db[n] += sum_m dY[m][n]; grid = (N/CW, ceil(M/RPB)), block = 256 (256/CW row phases x CW columns)
+#define COLSUM_RPB 128
 template <int CW>
 __global__ __launch_bounds__(256) void k_colsum(const bf16_t* __restrict__ dy, int M, int N, float* __restrict__ db) {
     constexpr int PH = 256 / CW;
     __shared__ float red[PH][CW];
     const int c = threadIdx.x % CW, col = blockIdx.x * CW + c, ph = threadIdx.x / CW;
-    const int r0 = blockIdx.y * 1024, r1 = min(M, r0 + 1024);
+    const int r0 = blockIdx.y * COLSUM_RPB, r1 = min(M, r0 + COLSUM_RPB);
     float acc = 0.f;
     for (int r = r0 + ph; r < r1; r += PH) acc += bf2f(dy[(long long)r * N + col]);
     red[ph][c] = acc;
@@ -107,8 +108,8 @@ DRL_API int drl_col2im(int layer, const void* dcol, const void* act_in, void* dx
 
 DRL_API int drl_colsum(const void* dy, int M, int N, float* db, hipStream_t s) {
     if (M <= 0 || N <= 0 || N % 32 != 0) return -1;
-    if (N % 64 == 0) k_colsum<64><<<dim3(N / 64, (M + 1023) / 1024), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
-    else k_colsum<32><<<dim3(N / 32, (M + 1023) / 1024), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
+    if (N % 64 == 0) k_colsum<64><<<dim3(N / 64, (M + COLSUM_RPB - 1) / COLSUM_RPB), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
+    else k_colsum<32><<<dim3(N / 32, (M + COLSUM_RPB - 1) / COLSUM_RPB), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
     return (int)hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define BK 64
 #define NTHREADS 256
 
-enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8 };
+enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16 };
 
 struct Epilogue {
     void* C;
@@ -40,7 +40,18 @@ struct Epilogue {
     long long ldmask;
     float scale;
     int flags;
+    // EPI_LSTM: the GEMM is h_prev . W_hh^T with gate-interleaved columns (n = 4*unit + {i,f,g,o}); the lane's 4
+    // consecutive outputs are exactly one unit's gates, so the whole cell update is lane-local.
+    const float* xg;        // [Mo][ldxg] x.W_ih^T + b_ih + b_hh for this time step (interleaved)
+    long long ldxg;
+    const float* c_prev;    // [Mo][No/4]
+    float* c_out;           // [Mo][No/4]
+    bf16_t* h_out;          // [Mo][No/4]
+    bf16_t* gates_out;      // [Mo][No] post-activation i,f,g,o (for BPTT), may be null
 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // ---------------------------------------------------------------------------------------------------
 // Operand functors: element address = row_base(r) + col_off(c)   (c multiple of 8; 8 elements never straddle
@@ -227,6 +238,17 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
                 float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
+            if (flags & EPI_LSTM) {
+                const float4 x = *reinterpret_cast<const float4*>(ep.xg + (long long)m * ep.ldxg + n);
+                const int H = No >> 2, u = n >> 2;
+                const float ig = sigmoidf_(v[0] + x.x), fg = sigmoidf_(v[1] + x.y), gg = tanhf_(v[2] + x.z), og = sigmoidf_(v[3] + x.w);
+                const float c = fg * ep.c_prev[(long long)m * H + u] + ig * gg;
+                ep.c_out[(long long)m * H + u] = c;
+                ep.h_out[(long long)m * H + u] = f2bf(og * tanhf_(c));
+                if (ep.gates_out)
+                    *reinterpret_cast<uint2*>(ep.gates_out + (long long)m * No + n) = make_uint2(pack_bf2(ig, fg), pack_bf2(gg, og));
+                continue;
+            }
             if (flags & EPI_RELU) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
@@ -281,6 +303,7 @@ typedef ConvOp<9, 9, 64, 3, 1, false> Conv3Op;
 static Epilogue make_epi(void* C, long long ldc, const float* bias, const void* mask, long long ldmask, float scale, int flags) {
     Epilogue e;
     e.C = C; e.ldc = ldc; e.bias = bias; e.mask = (const bf16_t*)mask; e.ldmask = ldmask; e.scale = scale; e.flags = flags;
+    e.xg = nullptr; e.ldxg = 0; e.c_prev = nullptr; e.c_out = nullptr; e.h_out = nullptr; e.gates_out = nullptr;
     return e;
 }
 
@@ -369,4 +392,15 @@ DRL_API int drl_conv_dcol(int layer, const void* dy, int frames, const void* w, 
         return launch<128, 64, 2, 2, false, true>(A, B, M, Conv3Op::K, 64, 1, make_epi(dcol, Conv3Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
     }
     return -1;
+}
+
+// ---- LSTM forward step: (h, c) <- cell(xg_t + h_prev . W_hh^T, c_prev), gate-interleaved layout -----------------
+// h_prev bf16 [M][H], w_hh bf16 [4H][H] (row n = 4*unit + gate), xg f32 [M][4H], c f32 [M][H].
+DRL_API int drl_lstm_step(const void* h_prev, const void* w_hh, const float* xg, const float* c_prev, void* h_out, float* c_out,
+                          void* gates_out, int M, int H, hipStream_t s) {
+    if (H % 64 != 0 || M <= 0) return -1;
+    Epilogue ep = make_epi(nullptr, 0, nullptr, nullptr, 0, 1.0f, EPI_LSTM);
+    ep.xg = xg; ep.ldxg = 4LL * H; ep.c_prev = c_prev; ep.c_out = c_out; ep.h_out = (bf16_t*)h_out; ep.gates_out = (bf16_t*)gates_out;
+    DenseOp A{(const bf16_t*)h_prev, H, M}, B{(const bf16_t*)w_hh, H, 4 * H};
+    return launch<64, 64, 2, 2, false, false>(A, B, M, 4 * H, H, 1, ep, s);
 }

@@ -115,14 +115,15 @@ __global__ __launch_bounds__(256) void k_head_bwd_dh(const float* __restrict__ d
 }
 
 // Weight grads, accumulated with fp32 atomics into ZEROED buffers.
-// grid = (4, ceil(M/128)); block = 256: thread owns hidden column k = blockIdx.x*256 + tid of the 1024.
+// grid = (4, ceil(M/DW_ROWS)); block = 256: thread owns hidden column k = blockIdx.x*256 + tid of the 1024.
+#define DW_ROWS 16
 __global__ __launch_bounds__(256) void k_head_bwd_dw(const float* __restrict__ dq, const bf16_t* __restrict__ h, int M, int A,
                                                     float* __restrict__ gw_adv, float* __restrict__ gb_adv /* may be null */,
                                                     float* __restrict__ gw_val, float* __restrict__ gb_val) {
-    __shared__ float s_d[128][MAX_A + 1];    // [r][0..A-1] = dadv, [r][A] = dval
-    const int r0 = blockIdx.y * 128;
-    const int nr = min(128, M - r0);
-    for (int i = threadIdx.x; i < 128 * (A + 1); i += 256) {
+    __shared__ float s_d[DW_ROWS][MAX_A + 1];    // [r][0..A-1] = dadv, [r][A] = dval
+    const int r0 = blockIdx.y * DW_ROWS;
+    const int nr = min(DW_ROWS, M - r0);
+    for (int i = threadIdx.x; i < DW_ROWS * (A + 1); i += 256) {
         int r = i / (A + 1), j = i % (A + 1);
         float v = 0.f;
         if (r < nr) {
@@ -176,6 +177,6 @@ DRL_API int drl_head_bwd(const float* dq, const void* h, int M, int A, const voi
                          float* gw_adv, float* gb_adv, float* gw_val, float* gb_val, hipStream_t s) {
     if (M <= 0 || A <= 0 || A > MAX_A) return -1;
     k_head_bwd_dh<<<(M + 3) / 4, 256, 0, s>>>(dq, (const bf16_t*)h, M, A, (const bf16_t*)w_adv, (const bf16_t*)w_val, (bf16_t*)dh);
-    k_head_bwd_dw<<<dim3(4, (M + 127) / 128), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
+    k_head_bwd_dw<<<dim3(4, (M + DW_ROWS - 1) / DW_ROWS), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,80 @@
+// LSTM backward-through-time pointwise kernel + small helpers (SURVEY G6 backward).
+// Forward steps and all GEMMs of the recurrence run on the MFMA kernel of gemm.hip (EPI_LSTM epilogue / NN split-K);
+// what is left per time step is elementwise over (batch, unit): combine the gradient arriving from the heads with
+// the recurrent one, push it through the cell, and emit d(gate pre-activations) in the gate-interleaved layout
+// the weight-gradient GEMMs consume.
+#include "common.h"
+
+// one thread per (b, unit).  gates = post-activation (i,f,g,o) saved by the forward epilogue.
+// dh_rec (f32) is read AND zeroed: the next (earlier) time step's split-K GEMM accumulates into it with atomics.
+__global__ __launch_bounds__(256) void k_lstm_bwd_point(const bf16_t* __restrict__ dh_head /* may be null */,
+                                                       float* __restrict__ dh_rec, float* __restrict__ dc,
+                                                       const bf16_t* __restrict__ gates, const float* __restrict__ c_t,
+                                                       const float* __restrict__ c_prev, bf16_t* __restrict__ dgates,
+                                                       int n /* B*H */, int H) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / H, u = i - b * H;
+    float dh = dh_rec[i];
+    dh_rec[i] = 0.f;
+    if (dh_head) dh += bf2f(dh_head[i]);
+    const uint2 gw = *reinterpret_cast<const uint2*>(gates + ((long long)b * H + u) * 4);
+    const float ig = __uint_as_float(gw.x << 16), fg = __uint_as_float(gw.x & 0xffff0000u);
+    const float gg = __uint_as_float(gw.y << 16), og = __uint_as_float(gw.y & 0xffff0000u);
+    const float tc = 2.0f / (1.0f + __expf(-2.0f * c_t[i])) - 1.0f;
+    const float dcell = dh * og * (1.0f - tc * tc) + dc[i];
+    const float d_o = dh * tc * og * (1.0f - og);
+    const float d_i = dcell * gg * ig * (1.0f - ig);
+    const float d_g = dcell * ig * (1.0f - gg * gg);
+    const float d_f = dcell * c_prev[i] * fg * (1.0f - fg);
+    dc[i] = dcell * fg;
+    *reinterpret_cast<uint2*>(dgates + ((long long)b * H + u) * 4) = make_uint2(pack_bf2(d_i, d_f), pack_bf2(d_g, d_o));
+}
+
+// frame byte offsets of a sampled sequence batch, time-major: off[t*B + b] = (idx[b]*T + t) * frame_bytes
+__global__ void k_seq_offsets(const int* __restrict__ idx, int B, int T, long long frame_bytes, long long* __restrict__ off) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    int t = i / B, b = i - t * B;
+    off[i] = ((long long)idx[b] * T + t) * frame_bytes;
+}
+
+// dst[b][:] = src[idx[b]][:]  (f32 rows -> f32 and bf16 copies): stored recurrent state of the sampled sequences
+__global__ void k_gather_state(const float* __restrict__ src, const int* __restrict__ idx, int B, int H,
+                               float* __restrict__ dst_f32, bf16_t* __restrict__ dst_bf16) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    int b = i / H, u = i - b * H;
+    float v = src[(long long)idx[b] * H + u];
+    if (dst_f32) dst_f32[i] = v;
+    if (dst_bf16) dst_bf16[i] = f2bf(v);
+}
+
+__global__ void k_add2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+DRL_API int drl_lstm_bwd_point(const void* dh_head, float* dh_rec, float* dc, const void* gates, const float* c_t,
+                               const float* c_prev, void* dgates, int B, int H, hipStream_t s) {
+    if (B <= 0 || H <= 0) return -1;
+    int n = B * H;
+    k_lstm_bwd_point<<<(n + 255) / 256, 256, 0, s>>>((const bf16_t*)dh_head, dh_rec, dc, (const bf16_t*)gates, c_t, c_prev,
+                                                     (bf16_t*)dgates, n, H);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_seq_offsets(const int* idx, int B, int T, long long frame_bytes, long long* off, hipStream_t s) {
+    if (B <= 0 || T <= 0) return -1;
+    k_seq_offsets<<<(B * T + 255) / 256, 256, 0, s>>>(idx, B, T, frame_bytes, off);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_gather_state(const float* src, const int* idx, int B, int H, float* dst_f32, void* dst_bf16, hipStream_t s) {
+    if (B <= 0 || H <= 0) return -1;
+    k_gather_state<<<(B * H + 255) / 256, 256, 0, s>>>(src, idx, B, H, dst_f32, (bf16_t*)dst_bf16);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_add2(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    if (n <= 0) return -1;
+    k_add2<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n);
+    return (int)hipGetLastError();
+}

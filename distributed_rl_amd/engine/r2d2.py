@@ -1,0 +1,239 @@
+"""R2D2Engine — graph-captured gfx950 recurrent learner step (replaces DuelingLSTMDQN.calc_priorities,
+libs/models.py:106-162, and the R2D2 use of the Learner loop, learner_node.py:32-45).
+
+The reference issues 315 single-step batch-64 forwards per update from Python. Here the time axis is
+batched wherever there is no recurrence:
+
+  sample B sequences → time-major frame offsets, stored (h0, c0)
+  per net (online, target):
+      torso over ALL T·B = 7 680 frames at once (3 implicit-GEMM convs reading uint8 straight from the replay)
+      ONE input GEMM  xg[T·B, 2048] = feat · W_ihᵀ + (b_ih + b_hh)
+      T recurrent steps: h·W_hhᵀ MFMA GEMM whose epilogue IS the LSTM cell (gate-interleaved weights → the four
+          gates of a unit land in one lane), saving post-activation gates for BPTT
+      heads over all T·B rows (FC 512→1024 + ReLU, dueling head)
+  one unroll of the online net yields both Q(s_t,·) and the n-steps-ahead argmax (the reference's ``self_cp``)
+  fused R2D2 TD (value rescale, η-mix priorities, masks for short sequences) → dL/dQ
+  backward over t ∈ [burn_in, T): heads → BPTT (split-K dG·W_hh GEMM + pointwise cell backward per step) →
+      dW_hh, dW_ih, dfeat as three big GEMMs over all learning steps → conv backward
+  [one flat RCCL all-reduce] → global-norm clip + Adam + bf16 re-cast → priority write-back
+
+Burn-in steps run the same kernels; gradients simply never flow past t = burn_in (models.py:125-137).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..config import R2D2Config
+from ..models import DuelingLSTMDQN
+from ..models.packing import ParamPack, r2d2_layout
+from ..ops import hip as H
+from ..replay.device_seq import DeviceSequenceReplay
+
+
+class SeqNetBuffers:
+    def __init__(self, T: int, B: int, Hd: int, n_action: int, device, save_gates: bool):
+        bf = dict(dtype=torch.bfloat16, device=device)
+        N = T * B
+        self.act1 = torch.zeros(N, 20, 20, 32, **bf)
+        self.act2 = torch.zeros(N, 9, 9, 64, **bf)
+        self.act3 = torch.zeros(N, 3136, **bf)
+        self.xg = torch.zeros(T, B, 4 * Hd, device=device)
+        self.hs = torch.zeros(T + 1, B, Hd, **bf)            # hs[0] = h0, hs[t+1] = h after step t
+        self.cs = torch.zeros(T + 1, B, Hd, device=device)
+        self.gates = torch.zeros(T, B, 4 * Hd, **bf) if save_gates else None
+        self.h2 = torch.zeros(N, 1024, **bf)
+        self.q = torch.zeros(N, n_action, device=device)
+
+
+class R2D2Engine:
+    def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
+                 init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
+                 done_offset: int = 0):
+        self.cfg, self.replay, self.dist = cfg, replay, dist
+        self.device = dev = torch.device(device)
+        self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
+        self.burn = cfg.burn_in
+        self.L = self.T - self.burn                       # backward window [burn, T)
+        self.done_offset = done_offset
+        B, T, Hd, L = self.B, self.T, self.Hd, self.L
+        model = init_model if init_model is not None else DuelingLSTMDQN(n_action, B, cfg.burn_in, cfg.nstep)
+        lay = r2d2_layout(n_action, hidden=Hd)
+        self.P = ParamPack(lay, dev)
+        self.P.load_state_dict(model.state_dict())
+        self.Pb = self.P.like(torch.bfloat16)
+        self.Tg = self.P.like()
+        self.Tb = self.P.like(torch.bfloat16)
+        self.G = self.P.like()
+        self.M1 = self.P.like()
+        self.M2 = self.P.like()
+        H.cast_bf16(self.P.flat, self.Pb.flat)
+        self.sync_target()
+        self.st = H.new_step_state(dev, cfg.beta0, cfg.beta_decay)
+        self.partial = torch.zeros(1024, device=dev)
+        self.n_partial = H.n_partials(self.P.flat.numel())
+        self.on = SeqNetBuffers(T, B, Hd, n_action, dev, True)
+        self.tg = SeqNetBuffers(T, B, Hd, n_action, dev, False)
+        self.bsum_on = torch.zeros(4 * Hd, device=dev)
+        self.bsum_tg = torch.zeros(4 * Hd, device=dev)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        NB = L * B
+        self.NB = NB
+        self.w = torch.zeros(B, device=dev)
+        self.dq = torch.zeros(T, B, n_action, device=dev)
+        self.new_prio = torch.zeros(B, device=dev)
+        self.dh2 = torch.zeros(NB, 1024, **bf)
+        self.dhs = torch.zeros(L, B, Hd, **bf)
+        self.dG = torch.zeros(L, B, 4 * Hd, **bf)
+        self.dh_rec = torch.zeros(B, Hd, device=dev)
+        self.dc = torch.zeros(B, Hd, device=dev)
+        self.d3 = torch.zeros(NB * 49, 64, **bf)
+        self.dcol3 = torch.zeros(NB * 49, 576, **bf)
+        self.d2 = torch.zeros(NB * 81, 64, **bf)
+        self.dcol2 = torch.zeros(NB * 81, 512, **bf)
+        self.d1 = torch.zeros(NB * 400, 32, **bf)
+        self.wgrad_splits = wgrad_splits
+        self.world = dist.world_size if dist is not None else 1
+        self.use_graph = use_graph
+        self._graphs = None
+        self.steps_done = 0
+
+    def sync_target(self) -> None:
+        self.Tg.flat.copy_(self.P.flat)
+        self.Tb.flat.copy_(self.Pb.flat)
+
+    # ---- forward of one net over the whole sampled batch ---------------------------------------------------
+    def _net_forward(self, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor) -> None:
+        r, T, B, Hd = self.replay, self.T, self.B, self.Hd
+        N = T * B
+        H.conv_fwd(1, r.frames, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, N, r.frame_off)
+        H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
+        H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, N)
+        H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
+        H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), buf.xg.view(N, 4 * Hd), N, 4 * Hd, 3136, bias=bsum,
+               flags=H.EPI_OUT_F32, big=True)
+        H.gather_state(r.h0, r.idx, None, buf.hs[0])
+        H.gather_state(r.c0, r.idx, buf.cs[0], None)
+        w_hh = wb.view("lstm.w_hh")
+        for t in range(T):
+            H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
+                        buf.gates[t] if buf.gates is not None else None)
+        H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
+               flags=H.EPI_RELU, big=True)
+        H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
+
+    def _forward_backward(self) -> None:
+        cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
+        H.step_begin(self.st, r.n_items)
+        r.sample(self.st)
+        self.G.flat.zero_()
+        self._net_forward(self.Pb, self.P, self.on, self.bsum_on)
+        self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
+        H.is_weights(r.prio, self.st, self.w)
+        H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,
+                  burn, cfg.nstep, self.done_offset, cfg.gamma_n, cfg.eta, cfg.rescale_eps, self.dq, self.new_prio)
+        # ---- backward over rows [burn*B, T*B) ----
+        G, Pb, on = self.G, self.Pb, self.on
+        r0 = burn * B
+        h2, hs_out = on.h2[r0:], on.hs[burn + 1:].view(NB, Hd)
+        H.head_bwd(self.dq.view(T * B, A)[r0:], h2, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh2, G.view("adv2.w"), None,
+                   G.view("val2.w"), G.view("val2.b"))
+        H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+        H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
+        H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
+        # BPTT
+        self.dh_rec.zero_()
+        self.dc.zero_()
+        w_hh = Pb.view("lstm.w_hh")
+        for t in range(T - 1, burn - 1, -1):
+            k = t - burn
+            H.lstm_bwd_point(self.dhs[k], self.dh_rec, self.dc, on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k])
+            if t > burn:
+                H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=16, big=False)
+        dG = self.dG.view(NB, 4 * Hd)
+        a3 = on.act3[r0:]
+        H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+        H.gemm(H.TN, dG, a3, G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
+        H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
+        G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
+        H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), self.d3.view(NB, 3136), NB, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
+        sp = self.wgrad_splits
+        a2, a1 = on.act2[r0:], on.act1[r0:]
+        H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), NB, splits=sp)
+        H.colsum(self.d3, G.view("conv3.b"), NB * 49, 64)
+        H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, NB)
+        H.col2im(3, self.dcol3, a2, self.d2, NB)
+        H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), NB, splits=sp)
+        H.colsum(self.d2, G.view("conv2.b"), NB * 81, 64)
+        H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, NB)
+        H.col2im(2, self.dcol2, a1, self.d1, NB)
+        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), NB, frame_off=r.frame_off[r0:], splits=2 * sp)
+        H.colsum(self.d1, G.view("conv1.b"), NB * 400, 32)
+
+    def _optimize(self) -> None:
+        cfg = self.cfg
+        H.grad_sumsq(self.G.flat, self.partial)
+        H.adam_step(self.P.flat, self.G.flat, self.M1.flat, self.M2.flat, self.Pb.flat, self.partial, self.n_partial,
+                    1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, self.st)
+        self.replay.update(self.new_prio)
+        H.step_end(self.st)
+
+    def _all_reduce(self) -> None:
+        if self.world > 1:
+            self.dist.all_reduce_flat(self.G.flat)
+
+    def _eager_step(self) -> None:
+        self._forward_backward()
+        self._all_reduce()
+        self._optimize()
+
+    def capture(self) -> None:
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_step()
+            self._graphs = ("one", g)
+        except Exception:
+            if self.world == 1:
+                raise
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._forward_backward()
+            with torch.cuda.graph(g2):
+                self._optimize()
+            self._graphs = ("split", g1, g2)
+        self.steps_done += 1
+
+    def step(self) -> None:
+        if self.use_graph:
+            if self._graphs is None:
+                self.capture()
+            if self._graphs[0] == "one":
+                self._graphs[1].replay()
+            else:
+                self._graphs[1].replay()
+                self._all_reduce()
+                self._graphs[2].replay()
+        else:
+            self._eager_step()
+        self.steps_done += 1
+        if self.steps_done % self.cfg.target_update == 0:
+            self.sync_target()
+
+    def stats(self) -> dict:
+        return H.read_step_state(self.st)
+
+    def state_dict(self):
+        return self.P.state_dict()
+
+    def load_state_dict(self, sd) -> None:
+        self.P.load_state_dict(sd)
+        H.cast_bf16(self.P.flat, self.Pb.flat)

@@ -59,6 +59,16 @@ def _conv_from_kernel(w: torch.Tensor) -> torch.Tensor:    # (O,kh,kw,I) → (O,
     return w.permute(0, 3, 1, 2).contiguous()
 
 
+def _gate_interleave(w: torch.Tensor, H: int) -> torch.Tensor:
+    """PyTorch LSTM row order [i(H); f(H); g(H); o(H)] -> kernel order n = 4*unit + gate, so one lane of the MFMA
+    accumulator (4 consecutive columns) holds all four gates of a unit (csrc/hip/gemm.hip EPI_LSTM)."""
+    return w.reshape(4, H, *w.shape[1:]).transpose(0, 1).reshape(4 * H, *w.shape[1:]).contiguous()
+
+
+def _gate_deinterleave(w: torch.Tensor, H: int) -> torch.Tensor:
+    return w.reshape(H, 4, *w.shape[1:]).transpose(0, 1).reshape(4 * H, *w.shape[1:]).contiguous()
+
+
 class Layout:
     """Ordered list of kernel-layout segments + pack/unpack rules against a reference state_dict."""
 
@@ -136,8 +146,9 @@ def r2d2_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
             "conv1.w": _conv_to_kernel(sd["conv1.weight"]), "conv1.b": sd["conv1.bias"],
             "conv2.w": _conv_to_kernel(sd["conv2.weight"]), "conv2.b": sd["conv2.bias"],
             "conv3.w": _conv_to_kernel(sd["conv3.weight"]), "conv3.b": sd["conv3.bias"],
-            "lstm.w_ih": _chw_cols_to_hwc(sd["lstm.weight_ih"], 64, fh, fw), "lstm.w_hh": sd["lstm.weight_hh"],
-            "lstm.b_ih": sd["lstm.bias_ih"], "lstm.b_hh": sd["lstm.bias_hh"],
+            "lstm.w_ih": _gate_interleave(_chw_cols_to_hwc(sd["lstm.weight_ih"], 64, fh, fw), H),
+            "lstm.w_hh": _gate_interleave(sd["lstm.weight_hh"], H),
+            "lstm.b_ih": _gate_interleave(sd["lstm.bias_ih"], H), "lstm.b_hh": _gate_interleave(sd["lstm.bias_hh"], H),
             "fc1.w": torch.cat([sd["adv1.weight"], sd["val1.weight"]], 0),
             "fc1.b": torch.cat([sd["adv1.bias"], sd["val1.bias"]], 0),
             "adv2.w": sd["adv2.weight"], "val2.w": sd["val2.weight"], "val2.b": sd["val2.bias"],
@@ -148,9 +159,9 @@ def r2d2_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
             ("conv1.weight", _conv_from_kernel(k["conv1.w"])), ("conv1.bias", k["conv1.b"].clone()),
             ("conv2.weight", _conv_from_kernel(k["conv2.w"])), ("conv2.bias", k["conv2.b"].clone()),
             ("conv3.weight", _conv_from_kernel(k["conv3.w"])), ("conv3.bias", k["conv3.b"].clone()),
-            ("lstm.weight_ih", _hwc_cols_to_chw(k["lstm.w_ih"], 64, fh, fw).contiguous()),
-            ("lstm.weight_hh", k["lstm.w_hh"].clone()),
-            ("lstm.bias_ih", k["lstm.b_ih"].clone()), ("lstm.bias_hh", k["lstm.b_hh"].clone()),
+            ("lstm.weight_ih", _hwc_cols_to_chw(_gate_deinterleave(k["lstm.w_ih"], H), 64, fh, fw).contiguous()),
+            ("lstm.weight_hh", _gate_deinterleave(k["lstm.w_hh"], H)),
+            ("lstm.bias_ih", _gate_deinterleave(k["lstm.b_ih"], H)), ("lstm.bias_hh", _gate_deinterleave(k["lstm.b_hh"], H)),
             ("adv1.weight", k["fc1.w"][:512].contiguous()), ("adv1.bias", k["fc1.b"][:512].clone()),
             ("adv2.weight", k["adv2.w"].clone()),
             ("val1.weight", k["fc1.w"][512:].contiguous()), ("val1.bias", k["fc1.b"][512:].clone()),

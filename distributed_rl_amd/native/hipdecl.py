@@ -31,6 +31,12 @@ SIGS = {
     "drl_conv_fwd": [I, P, P, I, P, P, P, I, P],
     "drl_conv_wgrad": [I, P, P, I, P, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
+    "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
+    # lstm.hip
+    "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
+    "drl_seq_offsets": [P, I, I, L, P, P],
+    "drl_gather_state": [P, P, I, I, P, P, P],
+    "drl_add2": [P, P, P, I, P],
     # conv_bwd.hip
     "drl_col2im": [I, P, P, P, I, P],
     "drl_colsum": [P, I, I, P, P],

@@ -245,3 +245,37 @@ def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
 
 def relu_mask(a: torch.Tensor, mask: torch.Tensor, out: torch.Tensor) -> None:
     _ck(native.hip().drl_relu_mask(_p(a), _p(mask), _p(out), a.numel(), _s()), "relu_mask")
+
+
+# ---- LSTM ----------------------------------------------------------------------------------------------
+def lstm_step(h_prev, w_hh, xg_t, c_prev, h_out, c_out, gates_out=None) -> None:
+    """One recurrent step on gate-interleaved weights: (h,c) <- cell(xg_t + h_prev·W_hhᵀ, c_prev)."""
+    M, Hd = h_prev.shape
+    _chk(h_prev, torch.bfloat16, "h_prev"); _chk(w_hh, torch.bfloat16, "w_hh"); _chk(xg_t, torch.float32, "xg_t")
+    _chk(c_prev, torch.float32, "c_prev"); _chk(h_out, torch.bfloat16, "h_out"); _chk(c_out, torch.float32, "c_out")
+    assert w_hh.shape == (4 * Hd, Hd) and xg_t.shape == (M, 4 * Hd)
+    _ck(native.hip().drl_lstm_step(_p(h_prev), _p(w_hh), _p(xg_t), _p(c_prev), _p(h_out), _p(c_out), _p(gates_out), M, Hd, _s()),
+        "lstm_step")
+
+
+def lstm_bwd_point(dh_head, dh_rec, dc, gates, c_t, c_prev, dgates) -> None:
+    B, Hd = c_t.shape
+    _chk(dh_rec, torch.float32, "dh_rec"); _chk(dc, torch.float32, "dc"); _chk(gates, torch.bfloat16, "gates")
+    _chk(dgates, torch.bfloat16, "dgates")
+    _ck(native.hip().drl_lstm_bwd_point(_p(dh_head), _p(dh_rec), _p(dc), _p(gates), _p(c_t), _p(c_prev), _p(dgates), B, Hd, _s()),
+        "lstm_bwd_point")
+
+
+def seq_offsets(idx, T: int, frame_bytes: int, off) -> None:
+    _chk(idx, torch.int32, "idx"); _chk(off, torch.int64, "off")
+    assert off.numel() >= idx.numel() * T
+    _ck(native.hip().drl_seq_offsets(_p(idx), idx.numel(), T, frame_bytes, _p(off), _s()), "seq_offsets")
+
+
+def gather_state(src, idx, dst_f32=None, dst_bf16=None) -> None:
+    _chk(src, torch.float32, "src"); _chk(idx, torch.int32, "idx")
+    _ck(native.hip().drl_gather_state(_p(src), _p(idx), idx.numel(), src.shape[-1], _p(dst_f32), _p(dst_bf16), _s()), "gather_state")
+
+
+def add2(a, b, out) -> None:
+    _ck(native.hip().drl_add2(_p(a), _p(b), _p(out), a.numel(), _s()), "add2")

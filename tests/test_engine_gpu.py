@@ -118,3 +118,93 @@ def test_device_per_block_ingest_roundtrip():
     assert np.array_equal(rep.frames[64 + 25].cpu().numpy(), blk["next_state"][29].reshape(-1))
     assert rep.total_prios() == pytest.approx(float(rep.tree[:64].sum()), rel=1e-6)
     assert int(rep.gen[0]) == 2 and int(rep.gen[59]) == 1
+
+
+# ---- R2D2 ------------------------------------------------------------------------------------------------
+def _r2d2_setup(B=8, burn=4, seq=8, n=2, A=4, cap=40, seed=0):
+    from distributed_rl_amd.config import R2D2Config
+    from distributed_rl_amd.engine.r2d2 import R2D2Engine
+    from distributed_rl_amd.models import DuelingLSTMDQN
+    from distributed_rl_amd.replay.device_seq import DeviceSequenceReplay
+    torch.manual_seed(seed)
+    cfg = R2D2Config(batch_size=B, burn_in=burn, seq_len=seq, nstep=n, target_update=10 ** 9)
+    model = DuelingLSTMDQN(A, B, burn, n)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    rep = DeviceSequenceReplay(cap, "cuda", cfg, seed=5)
+    rep.fill_synthetic(cap, n_action=A, seed=2)
+    T = cfg.total_len
+    # a few short, terminated sequences (padded + masked path)
+    g = torch.Generator().manual_seed(1)
+    lens = torch.full((cap,), T, dtype=torch.int32)
+    short = torch.arange(0, cap, 3)
+    lens[short] = torch.randint(burn + n + 1, T, (len(short),), generator=g).int()
+    done = torch.zeros(cap, T)
+    for s_ in short.tolist():
+        L = int(lens[s_])
+        done[s_, L - n:L] = 1.0
+    rep.length.copy_(lens)
+    rep.done.copy_(done)
+    eng = R2D2Engine(A, cfg, rep, "cuda", init_model=model, use_graph=False)
+    return model, cfg, rep, eng
+
+
+def test_r2d2_engine_step_matches_oracle():
+    from distributed_rl_amd.models import DuelingLSTMDQN
+    model, cfg, rep, eng = _r2d2_setup()
+    target = DuelingLSTMDQN(eng.A, cfg.batch_size, cfg.burn_in, cfg.nstep)
+    target.load_state_dict(model.state_dict())
+    eng._forward_backward()
+    torch.cuda.synchronize()
+    B, T = cfg.batch_size, cfg.total_len
+    idx = rep.idx.long().cpu()
+    frames = rep.frames.view(rep.capacity, T, 84, 84, 4)[idx.cuda()].permute(1, 0, 2, 3, 4).contiguous().cpu()
+    a = rep.act.cpu()[idx].t().long()
+    r = rep.rew.cpu()[idx].t()
+    d = rep.done.cpu()[idx].t()
+    lens = rep.length.cpu()[idx].long()
+    h0, c0 = rep.h0.cpu()[idx], rep.c0.cpu()[idx]
+    st = eng.stats()
+    w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"])
+    model.zero_grad()
+    td = model.sequence_td(target, frames, a, r, d, lens, h0, c0, w, cfg.eta, cfg.gamma_n, cfg.rescale_eps)
+    td.loss.backward()
+    with torch.no_grad():
+        q_ref, _ = model.unroll(frames, h0, c0, grad_from=T)
+    torch.testing.assert_close(eng.on.q.view(T, B, -1).cpu(), q_ref, rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(eng.tg.q.view(T, B, -1).cpu(), q_ref, rtol=5e-2, atol=5e-2)
+    assert st["loss"] == pytest.approx(float(td.loss.detach()), rel=8e-2, abs=5e-3)
+    torch.testing.assert_close(eng.new_prio.cpu(), td.prio, rtol=1e-1, atol=3e-2)
+    grads = eng.G.state_dict()
+    errs = {}
+    for name, p in model.named_parameters():
+        g, ref = grads[name], p.grad
+        errs[name] = (float((g - ref).norm() / (ref.norm() + 1e-12)), float(ref.norm()), float(g.norm()))
+    print(errs)
+    assert all(e[0] < 0.1 for e in errs.values()), errs
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, eps=cfg.adam_eps)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.grad.copy_(grads[name])
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
+    opt.step()
+    eng._optimize()
+    torch.cuda.synchronize()
+    assert eng.stats()["grad_norm"] == pytest.approx(float(gn), rel=1e-3)
+    new = eng.state_dict()
+    for name, p in model.named_parameters():
+        torch.testing.assert_close(new[name], p.detach(), rtol=1e-4, atol=2e-6)
+
+
+def test_r2d2_engine_graph_runs_and_learns():
+    _, cfg, rep, eng = _r2d2_setup(seed=3)
+    eng.use_graph = True
+    losses = []
+    for i in range(200):
+        eng.step()
+        losses.append(eng.stats()["loss"])
+    s = eng.stats()
+    assert eng._graphs[0] == "one" and s["step"] == 201
+    assert all(l == l for l in losses)
+    assert sum(losses[-20:]) < sum(losses[1:21]), (losses[1:21], losses[-20:])
