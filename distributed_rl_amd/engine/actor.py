@@ -100,6 +100,27 @@ class ActorEngine:
     def q_values(self) -> torch.Tensor:
         return self.buf.q
 
+    # ---- initial priorities of a block of fresh transitions (ape_x/actor.py:91-95; online == target, Q3) ----
+    def priorities(self, state: np.ndarray, next_state: np.ndarray, action: np.ndarray, reward: np.ndarray,
+                   done: np.ndarray, gamma_n: float, alpha: float = 0.6, prio_eps: float = 1e-5) -> np.ndarray:
+        K = int(action.shape[0])
+        dev = self.device
+        if getattr(self, "_pk", 0) != K:
+            self._pk = K
+            self._pbuf = TorsoBuffers(2 * K, self.A, dev)
+            self._pframes = torch.zeros(2 * K, 84, 84, 4, dtype=torch.uint8, device=dev)
+            self._pdq = torch.zeros(K, self.A, device=dev)
+            self._pprio = torch.zeros(K, device=dev)
+        self._pframes[:K].copy_(torch.from_numpy(np.ascontiguousarray(state)), non_blocking=True)
+        self._pframes[K:].copy_(torch.from_numpy(np.ascontiguousarray(next_state)), non_blocking=True)
+        torso_forward(self._pframes, None, 2 * K, self.Pb, self.P, self._pbuf)
+        a = torch.from_numpy(np.ascontiguousarray(action, dtype=np.int32)).to(dev)
+        r = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)).to(dev)
+        d = torch.from_numpy(np.ascontiguousarray(done, dtype=np.float32)).to(dev)
+        H.apex_td(self._pbuf.q, self._pbuf.q[K:], None, a, r, d, None, self.st, gamma_n, alpha, prio_eps, self._pdq,
+                  self._pprio, use_is=False)
+        return self._pprio.cpu().numpy()
+
     # ---- benchmarks -------------------------------------------------------------------------------------
     def step_synthetic(self) -> None:
         """One inference step on device-resident random frames (pure GPU path)."""

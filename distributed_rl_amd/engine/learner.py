@@ -1,0 +1,151 @@
+"""GPU learner process: the runtime around ApexEngine / R2D2Engine (replaces Learner.optimize_loop +
+the Replay thread of the reference, ape_x/learner.py:57-99, ape_x/replay.py:24-35, on an MI355X).
+
+Loop: bounded ingest from the experience channel straight into the HBM replay (no sleep-based back-pressure,
+SURVEY M5) → one graph replay per learner step → every ``publish_period`` steps / ``publish_interval`` seconds
+publish the flat fp32 parameters (versioned register; RCCL broadcast across GPUs) → periodic checkpoint in the
+reference's ``model_<t>.pth`` format (+ sidecar with optimizer moments, target net and step so ``--resume`` works).
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Optional
+
+import torch
+
+from ..config import ApexConfig, R2D2Config
+from ..models import DuelingDQN, DuelingLSTMDQN
+from ..transport import ExperienceChannel, ParamChannel
+
+
+class HipLearner:
+    def __init__(self, algorithm: str, n_action: int, cfg, exp: ExperienceChannel, params: ParamChannel, metrics=None,
+                 replay_size: int = 100_000, device="cuda", heartbeat=None, dist=None, use_graph: bool = True,
+                 publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0):
+        self.algorithm, self.cfg = algorithm, cfg
+        self.exp, self.params, self.metrics, self.heartbeat, self.dist = exp, params, metrics, heartbeat, dist
+        self.device = torch.device(device)
+        self.is_r2d2 = algorithm == "r2d2"
+        self.params.reset()
+        self.exp.reset()
+        if self.is_r2d2:
+            from ..replay.device_seq import DeviceSequenceReplay
+            from .r2d2 import R2D2Engine
+            self.replay = DeviceSequenceReplay(replay_size, self.device, cfg, seed=seed)
+            self.engine = R2D2Engine(n_action, cfg, self.replay, self.device, dist=dist, use_graph=use_graph)
+        else:
+            from ..replay.device_per import DevicePER
+            from .apex import ApexEngine
+            self.replay = DevicePER(replay_size, self.device, batch_size=cfg.batch_size, seed=seed)
+            self.engine = ApexEngine(n_action, cfg, self.replay, self.device, dist=dist, use_graph=use_graph)
+        self.publish_interval = publish_interval
+        self.max_blocks = max_blocks_per_step
+        self.step = 0
+        self._last_pub = 0.0
+        self.ingested = 0
+
+    # ---- pieces -------------------------------------------------------------------------------------
+    def ingest(self, max_blocks: Optional[int] = None) -> int:
+        n = 0
+        for blk in self.exp.drain(max_blocks or self.max_blocks):
+            n += self.replay.ingest_block(blk)
+        self.ingested += n
+        return n
+
+    def publish(self) -> int:
+        self._last_pub = time.time()
+        return self.params.publish(self.engine.P.flat.cpu().numpy())
+
+    def save(self, save_dir: str) -> str:
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, "model_%d.pth" % self.step)
+        torch.save(self.engine.state_dict(), path)                      # reference format (learner.py:98)
+        e = self.engine
+        aux = dict(step=self.step, engine="hip", algorithm=self.algorithm,
+                   target_flat=(e.T if not self.is_r2d2 else e.Tg).flat.cpu(),
+                   opt_flat=[t.flat.cpu() for t in ((e.SQ,) if not self.is_r2d2 else (e.M1, e.M2))],
+                   step_state=e.st.cpu())
+        torch.save(aux, path[:-4] + ".aux.pth")
+        return path
+
+    def resume(self, path: str) -> int:
+        from ..ops import hip as H
+        e = self.engine
+        e.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        aux_path = path[:-4] + ".aux.pth"
+        if os.path.exists(aux_path):
+            aux = torch.load(aux_path, map_location="cpu", weights_only=True)
+            self.step = int(aux["step"])
+            if aux.get("engine") == "hip":
+                tgt = e.T if not self.is_r2d2 else e.Tg
+                tgt.flat.copy_(aux["target_flat"])
+                H.cast_bf16(tgt.flat, e.Tb.flat)
+                for dst, src in zip(((e.SQ,) if not self.is_r2d2 else (e.M1, e.M2)), aux["opt_flat"]):
+                    dst.flat.copy_(src)
+                e.st.copy_(aux["step_state"])
+            else:
+                e.sync_target()
+        else:
+            e.sync_target()
+        e.steps_done = self.step
+        return self.step
+
+    def wait_memory(self, n: int, timeout: Optional[float] = None) -> bool:
+        t0 = time.time()
+        while len(self.replay) <= n:
+            if self.ingest(64) == 0:
+                time.sleep(0.01)
+            if timeout is not None and time.time() - t0 > timeout:
+                return False
+            if self.heartbeat is not None:
+                self.heartbeat.tick(self.step)
+        return True
+
+    # ---- main loop -------------------------------------------------------------------------------------
+    def optimize_loop(self, max_steps: Optional[int] = None, save_model_dir: str = "./models", stop_event=None,
+                      warmup_timeout: Optional[float] = None) -> int:
+        cfg = self.cfg
+        if not self.wait_memory(max(cfg.batch_size, cfg.start_memory_size), warmup_timeout):
+            raise TimeoutError("replay never reached the learn-start size")
+        end = None if max_steps is None else self.step + max_steps
+        t_last, n_last = time.time(), self.step
+        while end is None or self.step < end:
+            if stop_event is not None and stop_event.is_set():
+                break
+            t = self.step
+            self.ingest()
+            self.engine.step()
+            if t % cfg.publish_period == 0 and time.time() - self._last_pub >= self.publish_interval:
+                self.publish()
+            if t % cfg.fit_timing == 0:
+                now = time.time()
+                if self.metrics is not None:
+                    st = self.engine.stats()                             # one small D2H every fit_timing steps
+                    self.metrics.scalar("Q loss", t, st["loss"], force=True)
+                    self.metrics.scalar("Memory size", t, len(self.replay), force=True)
+                    if t > n_last:
+                        self.metrics.scalar("Updates per second", t, (t - n_last) / max(1e-9, now - t_last), force=True)
+                t_last, n_last = now, t
+                if self.heartbeat is not None:
+                    self.heartbeat.tick(t)
+            if t % cfg.save_timing == 0:
+                self.save(save_model_dir)
+            self.step += 1
+        torch.cuda.synchronize(self.device)
+        return self.step
+
+
+def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
+    from ..parallel.dist import Dist
+    dist = Dist(device=device) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+    learner = HipLearner(args.algorithm, n_action, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb, dist=dist,
+                         seed=args.seed or 0)
+    if args.resume:
+        learner.resume(args.resume)
+    learner.publish()
+    try:
+        learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir)
+    except KeyboardInterrupt:
+        pass
+    return 0

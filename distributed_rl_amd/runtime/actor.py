@@ -69,12 +69,13 @@ class _LocalApexBuffer:
 class Actor:
     def __init__(self, actor_no: int, env, policy_net, cfg, exp: ExperienceChannel, params: ParamChannel,
                  metrics=None, num_total_actors: int = 4, device=torch.device("cpu"), target_net=None,
-                 heartbeat=None, seed: Optional[int] = None, render_every: int = 0):
+                 heartbeat=None, seed: Optional[int] = None, render_every: int = 0, engine=None):
         self.no, self.env, self.cfg = actor_no, env, cfg
         self.E = env.E
         self.name = "actor_%d" % actor_no
         self.net = policy_net
         self.net.eval()
+        self.engine = engine          # optional engine.ActorEngine: gfx950 inference + on-device ε-greedy
         self.device = device
         self.exp, self.params, self.metrics = exp, params, metrics
         self.heartbeat = heartbeat
@@ -109,6 +110,9 @@ class Actor:
         if got is None:
             return False
         self._version, flat = got
+        if self.engine is not None:
+            self.engine.load_flat(flat)
+            return True
         self._pack.flat.copy_(torch.from_numpy(flat))
         self.net.load_state_dict(self._pack.state_dict(), strict=True)
         if self.is_r2d2:
@@ -118,6 +122,8 @@ class Actor:
     # ---- acting -----------------------------------------------------------------------------------
     @torch.no_grad()
     def act(self, obs_u8: np.ndarray) -> np.ndarray:
+        if self.engine is not None:
+            return self.engine.act(obs_u8)
         x = torch.from_numpy(obs_u8).to(self.device)
         q = self.net(x).float().cpu()
         greedy = q.argmax(1)
@@ -134,6 +140,11 @@ class Actor:
     def _publish_apex(self) -> None:
         blk = self.local.take(self.cfg.actor_batch)
         dev = self.device
+        if self.engine is not None:
+            blk["prio"] = self.engine.priorities(blk["state"], blk["next_state"], blk["action"], blk["reward"], blk["done"],
+                                                 self.cfg.gamma_n, self.cfg.per_alpha, self.cfg.prio_eps)
+            self._send(blk, codec.KIND_APEX)
+            return
         td = self.net.td_batch(self.net, torch.from_numpy(blk["state"]).to(dev), torch.from_numpy(blk["action"]).to(dev),
                                torch.from_numpy(blk["reward"]).to(dev), torch.from_numpy(blk["next_state"]).to(dev),
                                torch.from_numpy(blk["done"]).to(dev), None, self.cfg.per_alpha, self.cfg.gamma_n)

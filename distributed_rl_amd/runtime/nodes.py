@@ -56,6 +56,8 @@ def actor_main(argv=None) -> int:
     parser.add_argument('--num-envs', type=int, default=int(os.environ.get('DRL_NUM_ENVS', '1')), help='Envs per actor process.')
     parser.add_argument('--actor-batch', type=int, default=None)
     parser.add_argument('--param-period', type=int, default=None)
+    parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
+                        help='hip = batched gfx950 inference engine (Ape-X; needs a GPU).')
     _common(parser)
     args = parser.parse_args(argv)
     from .actor import Actor
@@ -66,8 +68,16 @@ def actor_main(argv=None) -> int:
     exp, par = connect(args.transport, args.run_id, create=False, host=args.redisserver)
     hb = _heartbeat(args, "actor", args.no)
     if args.algorithm == 'ape_x':
-        net = DuelingDQN(env.n_action).to(device)
-        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, heartbeat=hb, seed=args.seed)
+        engine = None
+        use_hip = args.engine == 'hip' or (args.engine == 'auto' and device.type == 'cuda')
+        net = DuelingDQN(env.n_action).to('cpu' if use_hip else device)
+        if use_hip:
+            from ..engine.actor import ActorEngine
+            from ..utils import epsilon_ladder
+            eps = epsilon_ladder(args.num_envs, (args.no - 1) * args.num_envs + 1, args.num_total_actors * args.num_envs)
+            engine = ActorEngine(env.n_action, args.num_envs, device, eps=eps, seed=args.seed or args.no, init_model=net)
+        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, heartbeat=hb, seed=args.seed,
+                      engine=engine)
     else:
         net = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)
         tgt = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)

@@ -1,0 +1,111 @@
+"""GPU runtime: HipLearner (HBM replay + graph-captured engine) fed by real actors through the transport;
+checkpoint in the reference format + resume; ActorEngine actions / priorities vs the PyTorch oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from distributed_rl_amd import envs  # noqa: E402
+from distributed_rl_amd.config import make_config  # noqa: E402
+from distributed_rl_amd.models import DuelingDQN, DuelingLSTMDQN  # noqa: E402
+from distributed_rl_amd.runtime.actor import Actor  # noqa: E402
+from distributed_rl_amd.transport import connect  # noqa: E402
+
+
+def test_actor_engine_matches_module():
+    from distributed_rl_amd.engine.actor import ActorEngine
+    torch.manual_seed(0)
+    m = DuelingDQN(6)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    eng = ActorEngine(6, 16, "cuda", eps=np.zeros(16, np.float32), init_model=m)
+    obs = np.random.default_rng(0).integers(0, 256, (16, 84, 84, 4), dtype=np.uint8)
+    a = eng.act(obs)
+    with torch.no_grad():
+        q = m(torch.from_numpy(obs))
+    torch.testing.assert_close(eng.q_values().cpu(), q, rtol=3e-2, atol=3e-2)
+    top2 = q.topk(2, 1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05
+    assert (torch.from_numpy(a)[clear] == q.argmax(1)[clear]).all()
+    a2 = eng.act(obs)                                        # graph replay path
+    assert (torch.from_numpy(a2)[clear] == q.argmax(1)[clear]).all()
+    # initial priorities (online == target)
+    rng = np.random.default_rng(1)
+    K = 20
+    s, s2 = rng.integers(0, 256, (2, K, 84, 84, 4), dtype=np.uint8)
+    act, rew, done = rng.integers(0, 6, K), rng.random(K).astype(np.float32), (rng.random(K) < 0.2).astype(np.float32)
+    pr = eng.priorities(s, s2, act, rew, done, 0.99, 0.6)
+    td = m.td_batch(m, torch.from_numpy(s), torch.from_numpy(act), torch.from_numpy(rew), torch.from_numpy(s2),
+                    torch.from_numpy(done), None, 0.6, 0.99)
+    np.testing.assert_allclose(pr, td.prio.detach().numpy(), rtol=0.15, atol=0.03)
+    # parameter refresh from a flat buffer
+    m2 = DuelingDQN(6)
+    from distributed_rl_amd.models import ParamPack
+    eng.load_flat(ParamPack.from_module(m2).flat.numpy())
+    eng.act(obs)
+    with torch.no_grad():
+        torch.testing.assert_close(eng.q_values().cpu(), m2(torch.from_numpy(obs)), rtol=5e-2, atol=5e-2)
+
+
+def test_hip_learner_apex_end_to_end(tmp_path, run_id):
+    from distributed_rl_amd.engine.actor import ActorEngine
+    from distributed_rl_amd.engine.learner import HipLearner
+    cfg = make_config("ape_x", batch_size=32, start_memory_size=64, actor_batch=16, save_timing=5, target_update=4,
+                      actor_param_period=10, fit_timing=5)
+    exp, par = connect("inproc", run_id, create=True)
+    learner = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=256, device="cuda", publish_interval=0.0)
+    v0 = learner.publish()
+    env = envs.make_vec("SyntheticCatch-v0", 8, seed=0)
+    net = DuelingDQN(4)
+    actor = Actor(1, env, net, cfg, exp, par, None, 2, torch.device("cuda"), seed=0,
+                  engine=ActorEngine(4, 8, "cuda", init_model=net, seed=1))
+    assert actor.pull_params() and actor._version == v0
+    actor.run(max_steps=60)
+    assert actor.published_blocks > 4
+    n = learner.optimize_loop(max_steps=11, save_model_dir=str(tmp_path), warmup_timeout=60)
+    assert n == 11 and len(learner.replay) > 64 and learner.ingested >= 64
+    st = learner.engine.stats()
+    assert st["step"] == 11 + 2 and np.isfinite(st["loss"])            # +2 warm-up steps of the graph capture
+    assert par.version() > v0
+    files = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_*.pth")) if "aux" not in p)
+    assert files == ["model_0.pth", "model_10.pth", "model_5.pth"]
+    ref = DuelingDQN(4)
+    ref.load_state_dict(torch.load(tmp_path / "model_10.pth", weights_only=True))      # reference-format checkpoint
+    # resume: parameters, optimizer moments, step counter
+    exp2, par2 = connect("inproc", run_id + "b", create=True)
+    l2 = HipLearner("ape_x", 4, cfg, exp2, par2, None, replay_size=256, device="cuda")
+    assert l2.resume(str(tmp_path / "model_10.pth")) == 10
+    torch.testing.assert_close(l2.engine.P.flat.cpu(), ref_flat(ref))
+    assert float(l2.engine.SQ.flat.abs().sum()) > 0 and l2.engine.stats()["step"] >= 10
+    # actor picks up the newer parameters
+    assert actor.pull_params() and actor._version == par.version()
+
+
+def ref_flat(module):
+    from distributed_rl_amd.models import ParamPack
+    return ParamPack.from_module(module).flat
+
+
+def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
+    from distributed_rl_amd.engine.learner import HipLearner
+    cfg = make_config("r2d2", batch_size=8, start_memory_size=10, actor_batch=2, save_timing=4, target_update=3, fit_timing=2)
+    cfg.burn_in, cfg.seq_len, cfg.overlap, cfg.nstep = 4, 8, 4, 2
+    exp, par = connect("inproc", run_id, create=True)
+    learner = HipLearner("r2d2", 4, cfg, exp, par, None, replay_size=64, device="cuda", publish_interval=0.0)
+    learner.publish()
+    env = envs.make_vec("SyntheticCatch-v0", 4, seed=0)
+    actor = Actor(1, env, DuelingLSTMDQN(4, 4, 4, 2), cfg, exp, par, None, 2, torch.device("cpu"),
+                  target_net=DuelingLSTMDQN(4, 4, 4, 2), seed=0)
+    actor.pull_params()
+    actor.run(max_steps=60)
+    n = learner.optimize_loop(max_steps=6, save_model_dir=str(tmp_path), warmup_timeout=60)
+    assert n == 6 and np.isfinite(learner.engine.stats()["loss"])
+    sd = torch.load(tmp_path / "model_4.pth", weights_only=True)
+    m = DuelingLSTMDQN(4, 8, 4, 2)
+    m.load_state_dict(sd)
+    assert tuple(sd["lstm.weight_hh"].shape) == (2048, 512)
