@@ -135,7 +135,7 @@ class ApexEngine:
         H.step_end(self.st)
 
     def _all_reduce(self) -> None:
-        if self.world > 1:
+        if self.dist is not None and self.dist.enabled:
             self.dist.all_reduce_flat(self.G.flat)
 
     # ---- step ---------------------------------------------------------------------------------------
@@ -154,15 +154,16 @@ class ApexEngine:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        try:
+        import os
+        collective = self.dist is not None and self.dist.enabled
+        if not collective or os.environ.get("DRL_GRAPH_COLLECTIVES") == "1":
+            # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._eager_step()
             self._graphs = ("one", g)
-        except Exception:
-            if self.world == 1:
-                raise
-            torch.cuda.synchronize()
+        else:
+            # default for multi-GPU: two graphs with the flat all-reduce issued eagerly between them
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._forward_backward()

@@ -32,7 +32,8 @@ class Dist:
         if device.type == "cuda":
             torch.cuda.set_device(device)
         self.backend = backend or ("nccl" if device.type == "cuda" else "gloo")
-        self.enabled = self.world_size > 1
+        # DRL_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
+        self.enabled = self.world_size > 1 or os.environ.get("DRL_FORCE_DIST") == "1"
         if self.enabled and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
