@@ -23,11 +23,19 @@
 //   * Epilogue fuses: x scale (uint8 frames: 1/255), + bias, ReLU, ReLU-backward mask, bf16 / f32 store, or f32
 //     atomic accumulation for split-K weight gradients.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-#define BK 64
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 #define NTHREADS 256
 
 enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16 };
@@ -61,55 +69,85 @@ struct DenseOp {
     const bf16_t* p;
     long long ld;
     int rows;
-    __device__ __forceinline__ long long row_base(int r) const { return r < rows ? (long long)r * ld : -1; }
+    typedef unsigned off_t;  // element offsets of a dense operand fit 32 bits (checked on the host): 1 VGPR per address
+    __device__ __forceinline__ bool row_ok(int r) const { return r < rows; }
+    __device__ __forceinline__ off_t row_base(int r) const { return (off_t)r * (off_t)ld; }
     __device__ __forceinline__ int col_off(int c) const { return c; }
-    __device__ __forceinline__ uint4 load8(long long off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    typedef uint4 raw_t;     // 8 bf16
+    __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
+    __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
 };
 
 // Implicit im2col of an NHWC tensor: logical matrix col[M = frames*OH*OW][K = KS*KS*C], K ordered (kh, kw, c).
 // U8 = source is raw uint8 frames (conv1): 8 elements = 8 bytes, widened to bf16 on load (exact for 0..255; the
 // 1/255 lives in the epilogue scale). frame_off (optional) = byte/element offset of each frame: conv1 reads straight
 // out of the replay store through the sampled indices — no gather copy.
-template <int H_, int W_, int C_, int KS_, int S_, bool U8_>
+template <int H_, int W_, int C_, int KS_, int S_, bool U8_, bool OFF_ = false>
 struct ConvOp {
     static constexpr int H = H_, W = W_, C = C_, KS = KS_, S = S_;
     static constexpr int OH = (H_ - KS_) / S_ + 1, OW = (W_ - KS_) / S_ + 1, KWC = KS_ * C_, K = KS_ * KS_ * C_;
     const void* x;
     const long long* frame_off;
     int rows;    // frames*OH*OW
-    __device__ __forceinline__ long long row_base(int m) const {
-        if (m >= rows) return -1;
-        int b = m / (OH * OW), rem = m - b * (OH * OW);
-        int oy = rem / OW, ox = rem - oy * OW;
-        long long fb = frame_off ? frame_off[b] : (long long)b * (H * W * C);
-        return fb + ((long long)(oy * S) * W + ox * S) * C;
+    // frames addressed through frame_off live in a >4 GB replay store: 64-bit offsets; dense batches fit 32 bits
+    typedef typename std::conditional<OFF_, long long, unsigned>::type off_t;
+    __device__ __forceinline__ bool row_ok(int m) const { return m < rows; }
+    __device__ __forceinline__ off_t row_base(int m) const {      // branch-free (see Stage::load)
+        const int mm = m < rows ? m : 0;
+        const int b = mm / (OH * OW), rem = mm - b * (OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        off_t fb;
+        if constexpr (OFF_) fb = frame_off[b];
+        else fb = (off_t)b * (off_t)(H * W * C);
+        return fb + (off_t)(((oy * S) * W + ox * S) * C);
     }
     __device__ __forceinline__ int col_off(int kc) const {
         int kh = kc / KWC;
         return kh * (W * C) + (kc - kh * KWC);
     }
-    __device__ __forceinline__ uint4 load8(long long off) const {
-        if (U8_) {
-            uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(x) + off);
+    // raw 8 elements as they sit in memory (8 bytes for uint8 frames, 16 for bf16); widened to bf16 only when the
+    // tile is written to LDS, so the global loads stay in flight across the MFMA phase instead of being consumed
+    // by the conversion right after issue.
+    struct raw_u8 { uint2 v; };
+    typedef typename std::conditional<U8_, uint2, uint4>::type raw_t;
+    __device__ __forceinline__ raw_t load_raw(off_t off) const {
+        if constexpr (U8_) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(x) + off);
+        else return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + off);
+    }
+    __device__ static __forceinline__ raw_t zero_raw() {
+        if constexpr (U8_) return make_uint2(0, 0);
+        else return make_uint4(0, 0, 0, 0);
+    }
+    __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) {
+        if constexpr (U8_) {
+            // v_cvt_f32_ubyteN per byte, then ONE v_perm_b32 per pair takes the two high halves (exact: 0..255 fit bf16)
             uint32_t o[4];
-            uint32_t w[2] = {v.x, v.y};
+            const uint32_t w[2] = {v.x, v.y};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint32_t b0 = (w[i >> 1] >> ((i & 1) * 16)) & 0xff, b1 = (w[i >> 1] >> ((i & 1) * 16 + 8)) & 0xff;
-                o[i] = (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
+                const uint32_t ww = w[i >> 1];
+                const float f0 = (i & 1) ? (float)((ww >> 16) & 0xffu) : (float)(ww & 0xffu);
+                const float f1 = (i & 1) ? (float)(ww >> 24) : (float)((ww >> 8) & 0xffu);
+                o[i] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
             }
             return make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            return v;
         }
-        return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + off);
     }
 };
 
 // ---------------------------------------------------------------------------------------------------
 // LDS tile layouts
 // ---------------------------------------------------------------------------------------------------
-// normal tile [R][64] bf16: 128-B rows, 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)
-__device__ __forceinline__ int nrm_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-// TR tile [64][R] bf16: rows of 2R bytes = U=R/16 units of 32 B; unit u of row k lives at u ^ f(k)
+// normal tile [R][BKT] bf16, stored as BKT/64 sub-tiles of [R][64] (128-B rows); inside a sub-tile the 16-B chunk c
+// of row r lives at chunk c ^ ((r>>1)&7)  -> ds_read_b128 of 16 consecutive rows at one chunk is conflict-free.
+template <int R>
+__device__ __forceinline__ int nrm_off(int r, int c) {
+    return (c >> 3) * (R * 128) + r * 128 + (((c & 7) ^ ((r >> 1) & 7)) << 4);
+}
+// TR tile [BKT][R] bf16: rows of 2R bytes = U=R/16 units of 32 B; unit u of row k lives at u ^ f(k)
 template <int R>
 __device__ __forceinline__ int tr_off(int k, int unit) {
     constexpr int U = R / 16;
@@ -117,38 +155,74 @@ __device__ __forceinline__ int tr_off(int k, int unit) {
     return k * (2 * R) + (((unit ^ ((k >> SH) & (U - 1))) & (U - 1)) << 5);
 }
 
-template <int OUT, bool TR, class Op>
+// Rows of a normal-orientation tile never change along K: their base offsets (and validity) are computed once per
+// workgroup and shared by every register set of the prefetch ring.
+template <int OUT, bool TR, int BKT, class Op>
+struct RowCache {
+    static constexpr int ROWS = TR ? BKT : OUT, COLS = TR ? OUT : BKT, CPR = COLS / 8;
+    static constexpr int NCH = (ROWS * CPR) / NTHREADS;
+    typename Op::off_t base[TR ? 1 : NCH];
+    unsigned ok;
+    __device__ __forceinline__ void init(const Op& op, int out0, int tid) {
+        ok = 0;
+        if constexpr (!TR) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int r = out0 + (tid + i * NTHREADS) / CPR;
+                base[i] = op.row_base(r);
+                ok |= (op.row_ok(r) ? 1u : 0u) << i;
+            }
+        }
+    }
+};
+
+template <int OUT, bool TR, int BKT, class Op>
 struct Stage {
-    static constexpr int ROWS = TR ? BK : OUT, COLS = TR ? OUT : BK, CPR = COLS / 8;
+    static constexpr int ROWS = TR ? BKT : OUT, COLS = TR ? OUT : BKT, CPR = COLS / 8;
     static constexpr int NCH = (ROWS * CPR) / NTHREADS;
     static_assert(NCH >= 1 && (ROWS * CPR) % NTHREADS == 0, "tile too small for 256 threads");
-    uint4 reg[NCH];
-    // out0 = first out index of the tile, k0 = first contraction index
-    __device__ __forceinline__ void load(const Op& op, int out0, int k0, int tid) {
+    typename Op::raw_t reg[NCH];
+    unsigned valid;
+    // out0 = first out index of the tile, k0 = first contraction index, Kc = contraction length. BRANCH-FREE on
+    // purpose: out-of-range rows / k (and whole inactive tiles past the end of the K range) read element 0 of the
+    // operand and are zeroed when the tile is written to LDS. With no control flow around the loads hipcc keeps
+    // counted s_waitcnt vmcnt(N) and the register ring really stays in flight (conditional loads made it fall back
+    // to vmcnt(0) everywhere).
+    __device__ __forceinline__ void load(const Op& op, const RowCache<OUT, TR, BKT, Op>& rc, int out0, int k0, int Kc, int tid,
+                                         bool active) {
+        valid = 0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int id = tid + i * NTHREADS, r = id / CPR, c = id % CPR;
-            long long rb = op.row_base((TR ? k0 : out0) + r);
-            reg[i] = rb >= 0 ? op.load8(rb + op.col_off((TR ? out0 : k0) + c * 8)) : make_uint4(0, 0, 0, 0);
+            const int id = tid + i * NTHREADS, r = id / CPR, c = id % CPR;
+            const int kidx = TR ? k0 + r : k0 + c * 8;
+            typename Op::off_t rb;
+            bool ok = active && kidx < Kc;
+            if constexpr (TR) { rb = op.row_base(kidx); ok = ok && op.row_ok(kidx); }
+            else { rb = rc.base[i]; ok = ok && ((rc.ok >> i) & 1u); }
+            const typename Op::off_t off = ok ? rb + (typename Op::off_t)op.col_off(TR ? out0 + c * 8 : kidx) : 0;
+            reg[i] = op.load_raw(off);
+            valid |= (ok ? 1u : 0u) << i;
         }
     }
     __device__ __forceinline__ void store(uint8_t* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int id = tid + i * NTHREADS, r = id / CPR, c = id % CPR;
-            int off = TR ? (tr_off<OUT>(r, c >> 1) + ((c & 1) << 4)) : nrm_off(r, c);
-            *reinterpret_cast<uint4*>(lds + off) = reg[i];
+            const int id = tid + i * NTHREADS, r = id / CPR, c = id % CPR;
+            const int off = TR ? (tr_off<OUT>(r, c >> 1) + ((c & 1) << 4)) : nrm_off<OUT>(r, c);
+            uint4 v = Op::to_bf16x8(reg[i]);
+            if (!((valid >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(lds + off) = v;
         }
     }
 };
 
 // fragment of 16 out-indices [o0, o0+16) x 32 contraction indices of k-step ks, as the MFMA wants it:
-// lane l holds out index o0 + (l&15), contraction 8*(l>>4) + j, j = 0..7
+// lane l holds out index o0 + (l&15), contraction 32*ks + 8*(l>>4) + j, j = 0..7
 template <int OUT, bool TR>
 __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, int lane) {
     if (!TR) {
         int r = o0 + (lane & 15), c = ks * 4 + (lane >> 4);
-        return *reinterpret_cast<const bf16x8*>(lds + nrm_off(r, c));
+        return *reinterpret_cast<const bf16x8*>(lds + nrm_off<OUT>(r, c));
     } else {
         int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
         int k1 = ks * 32 + 8 * g + q, k2 = k1 + 4, unit = o0 >> 4;
@@ -161,15 +235,21 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The kernel. grid = (tiles_n, tiles_m, splits). Contraction length Kc is processed in BK tiles; split z handles
+// The kernel. grid = (tiles_n, tiles_m, splits). Contraction length Kc is processed in BKT tiles; split z handles
 // tiles [z*kt_per, min((z+1)*kt_per, nkt)).
+//   BKT : K-tile (64 / 128 / 256). The small-grid GEMMs of the Ape-X step have ~1 workgroup per CU, so the fixed
+//         per-tile chain (ds_read latency -> MFMA -> ds_write -> barrier, ~500 cycles measured) is amortised over
+//         more MFMAs per barrier instead of being hidden by occupancy.
+//   D   : depth of the register prefetch ring (even): while tile k is multiplied out of LDS, the global loads of
+//         tiles k+1 .. k+D-1 are in flight in D-1 register sets.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, class AOp, class BOp>
+template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
 __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(D >= 2 && D % 2 == 0, "ring depth");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;    // MFMA tiles per wave
     static_assert(TM >= 1 && TN >= 1, "wave tile");
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     auto As = [&](int i) -> uint8_t* { return smem + i * (A_BYTES + B_BYTES); };
     auto Bs = [&](int i) -> uint8_t* { return smem + i * (A_BYTES + B_BYTES) + A_BYTES; };
@@ -177,7 +257,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int nkt = (Kc + BK - 1) / BK;
+    const int nkt = (Kc + BKT - 1) / BKT;
     const int kt0 = blockIdx.z * kt_per, kt1 = min(kt0 + kt_per, nkt);
     if (kt0 >= kt1) return;
 
@@ -187,28 +267,34 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Stage<BM, A_TR, AOp> sa;
-    Stage<BN, B_TR, BOp> sb;
-    sa.load(aop, m0, kt0 * BK, tid);
-    sb.load(bop, n0, kt0 * BK, tid);
-    sa.store(As(0), tid);
-    sb.store(Bs(0), tid);
+    RowCache<BM, A_TR, BKT, AOp> ra;
+    RowCache<BN, B_TR, BKT, BOp> rb;
+    ra.init(aop, m0, tid);
+    rb.init(bop, n0, tid);
+    Stage<BM, A_TR, BKT, AOp> sa[D];
+    Stage<BN, B_TR, BKT, BOp> sb[D];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        sa[s].load(aop, ra, m0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1);
+        sb[s].load(bop, rb, n0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1);
+    }
+    sa[0].store(As(0), tid);
+    sb[0].store(Bs(0), tid);
     __syncthreads();
 
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            sa.load(aop, m0, (kt + 1) * BK, tid);
-            sb.load(bop, n0, (kt + 1) * BK, tid);
-        }
+    // one K-tile: refill register set S with tile cur+D, multiply tile cur out of LDS buffer S&1 (D is even), move
+    // tile cur+1 from its register set into the other LDS buffer, barrier.
+    auto substep = [&](auto sc, int cur) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        sa[S].load(aop, ra, m0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
+        sb[S].load(bop, rb, n0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_TR>(As(cur), wm * (BM / WM) + i * 16, ks, lane);
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_TR>(As(S & 1), wm * (BM / WM) + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_TR>(Bs(cur), wn * (BN / WN) + j * 16, ks, lane);
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_TR>(Bs(S & 1), wn * (BN / WN) + j * 16, ks, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -216,15 +302,41 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, bf[j]),
                                                                         __builtin_bit_cast(mfma_bf16x8, af[i]), acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            sa.store(As(cur ^ 1), tid);
-            sb.store(Bs(cur ^ 1), tid);
-        }
+        sa[(S + 1) % D].store(As((S + 1) & 1), tid);   // tile cur+1 (zeros past the end: never read)
+        sb[(S + 1) % D].store(Bs((S + 1) & 1), tid);
         __syncthreads();
+    };
+    int kt = kt0;
+    // steady state: whole groups of D tiles, no control flow inside (keeps hipcc's vmcnt counting exact)
+    for (; kt + D <= kt1; kt += D) static_for<0, D>([&](auto sc) __attribute__((always_inline)) { substep(sc, kt + decltype(sc)::value); });
+    // tail: fewer than D tiles left
+    static_for<0, D>([&](auto sc) __attribute__((always_inline)) { if (kt + decltype(sc)::value < kt1) substep(sc, kt + decltype(sc)::value); });
+
+    const int flags = ep.flags;
+    if (flags & EPI_ATOMIC) {
+        // split-K accumulation: stage the f32 tile through LDS so every atomic wave-instruction adds 256 CONTIGUOUS
+        // bytes of one output row (full-rate shape, guide Guideline 12); the fragment layout itself (16 rows x 4
+        // scattered dwords per instruction) measured ~6x slower and dominated the weight-gradient kernels.
+        constexpr int LDC = BN + 4;
+        float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ml = wm * (BM / WM) + i * 16 + (lane & 15), nl = wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<float4*>(tile + ml * LDC + nl) =
+                    make_float4(acc[i][j][0] * ep.scale, acc[i][j][1] * ep.scale, acc[i][j][2] * ep.scale, acc[i][j][3] * ep.scale);
+            }
+        __syncthreads();
+        float* C = reinterpret_cast<float*>(ep.C);
+        for (int idx = tid; idx < BM * BN; idx += NTHREADS) {
+            const int ml = idx / BN, nl = idx - ml * BN;
+            if (m0 + ml < Mo) atomicAdd(C + (long long)(m0 + ml) * ep.ldc + n0 + nl, tile[ml * LDC + nl]);
+        }
+        return;
     }
 
     // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = tile col 4*(lane>>4)
-    const int flags = ep.flags;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
@@ -262,12 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
             }
             if (flags & EPI_OUT_F32) {
                 float* c = reinterpret_cast<float*>(ep.C) + (long long)m * ep.ldc + n;
-                if (flags & EPI_ATOMIC) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) atomicAdd(c + t, v[t]);
-                } else {
-                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 bf16_t* c = reinterpret_cast<bf16_t*>(ep.C) + (long long)m * ep.ldc + n;
                 *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
@@ -276,27 +383,32 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, class AOp, class BOp>
+template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
 static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s) {
     if (No % BN != 0 || Mo <= 0 || Kc <= 0) return -2;
-    const int nkt = (Kc + BK - 1) / BK;
+    const int nkt = (Kc + BKT - 1) / BKT;
     if (splits < 1) splits = 1;
     if (splits > nkt) splits = nkt;
     const int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;
     if (splits > 1 && !(ep.flags & EPI_ATOMIC)) return -3;
     dim3 grid(No / BN, (Mo + BM - 1) / BM, splits);
-    const size_t lds = 2 * (BM + BN) * BK * 2;
-    auto kern = k_gemm<BM, BN, WM, WN, A_TR, B_TR, AOp, BOp>;
+    size_t lds = 2 * (size_t)(BM + BN) * BKT * 2;
+    if ((ep.flags & EPI_ATOMIC) && lds < (size_t)BM * (BN + 4) * 4) lds = (size_t)BM * (BN + 4) * 4;
+    auto kern = k_gemm<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>;
     if (lds > 64 * 1024) {
         static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+        if (!once) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -6;
+            once = true;
+        }
     }
     kern<<<grid, NTHREADS, lds, s>>>(a, b, Mo, No, Kc, kt_per, ep);
     return (int)hipGetLastError();
 }
 
-typedef ConvOp<84, 84, 4, 8, 4, true> Conv1Op;
+typedef ConvOp<84, 84, 4, 8, 4, true, false> Conv1Op;
+typedef ConvOp<84, 84, 4, 8, 4, true, true> Conv1OffOp;
 typedef ConvOp<20, 20, 32, 4, 2, false> Conv2Op;
 typedef ConvOp<9, 9, 64, 3, 1, false> Conv3Op;
 
@@ -311,29 +423,41 @@ static Epilogue make_epi(void* C, long long ldc, const float* bias, const void* 
 // mode 0 (NT): C[M][N] = A[M][K] . W[N][K]^T          a = A (ld lda), b = W (ld ldb)
 // mode 1 (NN): C[M][N] = A[M][K] . B[K][N]            a = A, b = B [K][N]
 // mode 2 (TN): C[M][N] = A[K][M]^T . B[K][N]          a = A [K][M], b = B [K][N]   (contraction over memory rows)
-// big != 0 selects the 128x128 tile (needs N % 128 == 0), else 64x64.
-DRL_API int drl_gemm(int mode, int big, const void* a, long long lda, const void* b, long long ldb, int M, int N, int K,
+// variant: 0 = 64x64x64 ring 4 | 1 = 128x128x64 ring 2 | 2 = 64x64x128 ring 2 | 3 = 64x64x256 ring 2 | 4 = 128x64x128 ring 2
+template <bool A_TR, bool B_TR>
+static int dense_dispatch(int variant, const DenseOp& A, const DenseOp& B, int M, int N, int K, int splits, const Epilogue& ep,
+                          hipStream_t s) {
+    switch (variant) {
+        case 0: return launch<64, 64, 64, 2, 2, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
+        case 1: return launch<128, 128, 64, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
+        case 2: return launch<64, 64, 128, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
+        case 3: return launch<64, 64, 256, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
+        case 4: return launch<128, 64, 128, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
+    }
+    return -7;
+}
+
+DRL_API int drl_gemm(int mode, int variant, const void* a, long long lda, const void* b, long long ldb, int M, int N, int K,
                      void* C, long long ldc, const float* bias, const void* mask, long long ldmask, float scale, int flags,
                      int splits, hipStream_t s) {
     if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 3)) return -4;
+    if ((long long)M * lda >= (1LL << 32) || (long long)K * lda >= (1LL << 32) || (long long)N * ldb >= (1LL << 32) || (long long)K * ldb >= (1LL << 32)) return -8;
     Epilogue ep = make_epi(C, ldc, bias, mask, ldmask, scale, flags);
     const bf16_t* pa = (const bf16_t*)a;
     const bf16_t* pb = (const bf16_t*)b;
+    const int bm = (variant == 1 || variant == 4) ? 128 : 64;
     if (mode == 0) {
-        if (K % BK) return -5;
+        if (K % 8) return -5;
         DenseOp A{pa, lda, M}, B{pb, ldb, N};
-        return big ? launch<128, 128, 2, 2, false, false>(A, B, M, N, K, splits, ep, s)
-                   : launch<64, 64, 2, 2, false, false>(A, B, M, N, K, splits, ep, s);
+        return dense_dispatch<false, false>(variant, A, B, M, N, K, splits, ep, s);
     } else if (mode == 1) {
-        if (K % BK) return -5;
+        if (K % 8) return -5;
         DenseOp A{pa, lda, M}, B{pb, ldb, K};
-        return big ? launch<128, 128, 2, 2, false, true>(A, B, M, N, K, splits, ep, s)
-                   : launch<64, 64, 2, 2, false, true>(A, B, M, N, K, splits, ep, s);
+        return dense_dispatch<false, true>(variant, A, B, M, N, K, splits, ep, s);
     } else if (mode == 2) {
-        if (M % (big ? 128 : 64)) return -5;
+        if (M % bm) return -5;
         DenseOp A{pa, lda, K}, B{pb, ldb, K};
-        return big ? launch<128, 128, 2, 2, true, true>(A, B, M, N, K, splits, ep, s)
-                   : launch<64, 64, 2, 2, true, true>(A, B, M, N, K, splits, ep, s);
+        return dense_dispatch<true, true>(variant, A, B, M, N, K, splits, ep, s);
     }
     return -1;
 }
@@ -344,17 +468,23 @@ DRL_API int drl_conv_fwd(int layer, const void* x, const long long* frame_off, i
                          void* out, int relu, hipStream_t s) {
     const int fl = relu ? EPI_RELU : 0;
     if (layer == 1) {
-        Conv1Op A{x, frame_off, frames * Conv1Op::OH * Conv1Op::OW};
         DenseOp B{(const bf16_t*)w, Conv1Op::K, 32};
-        return launch<128, 32, 4, 1, false, false>(A, B, A.rows, 32, Conv1Op::K, 1, make_epi(out, 32, bias, nullptr, 0, 1.0f / 255.0f, fl), s);
+        const int rows = frames * Conv1Op::OH * Conv1Op::OW;
+        const Epilogue ep = make_epi(out, 32, bias, nullptr, 0, 1.0f / 255.0f, fl);
+        if (frame_off) {
+            Conv1OffOp A{x, frame_off, rows};
+            return launch<128, 32, 64, 4, 1, false, false, 4>(A, B, rows, 32, Conv1Op::K, 1, ep, s);
+        }
+        Conv1Op A{x, nullptr, rows};
+        return launch<128, 32, 64, 4, 1, false, false, 4>(A, B, rows, 32, Conv1Op::K, 1, ep, s);
     } else if (layer == 2) {
         Conv2Op A{x, frame_off, frames * Conv2Op::OH * Conv2Op::OW};
         DenseOp B{(const bf16_t*)w, Conv2Op::K, 64};
-        return launch<128, 64, 2, 2, false, false>(A, B, A.rows, 64, Conv2Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
+        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv2Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
     } else if (layer == 3) {
         Conv3Op A{x, frame_off, frames * Conv3Op::OH * Conv3Op::OW};
         DenseOp B{(const bf16_t*)w, Conv3Op::K, 64};
-        return launch<128, 64, 2, 2, false, false>(A, B, A.rows, 64, Conv3Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
+        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv3Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
     }
     return -1;
 }
@@ -365,17 +495,23 @@ DRL_API int drl_conv_wgrad(int layer, const void* x, const long long* frame_off,
                            int splits, hipStream_t s) {
     const int fl = EPI_OUT_F32 | EPI_ATOMIC;
     if (layer == 1) {
-        Conv1Op B{x, frame_off, frames * Conv1Op::OH * Conv1Op::OW};
-        DenseOp A{(const bf16_t*)dy, 32, B.rows};
-        return launch<32, 64, 1, 4, true, true>(A, B, 32, Conv1Op::K, B.rows, splits, make_epi(dw, Conv1Op::K, nullptr, nullptr, 0, 1.0f / 255.0f, fl), s);
+        const int rows = frames * Conv1Op::OH * Conv1Op::OW;
+        DenseOp A{(const bf16_t*)dy, 32, rows};
+        const Epilogue ep = make_epi(dw, Conv1Op::K, nullptr, nullptr, 0, 1.0f / 255.0f, fl);
+        if (frame_off) {
+            Conv1OffOp B{x, frame_off, rows};
+            return launch<32, 64, 128, 1, 4, true, true, 4>(A, B, 32, Conv1Op::K, rows, splits, ep, s);
+        }
+        Conv1Op B{x, nullptr, rows};
+        return launch<32, 64, 128, 1, 4, true, true, 4>(A, B, 32, Conv1Op::K, rows, splits, ep, s);
     } else if (layer == 2) {
         Conv2Op B{x, frame_off, frames * Conv2Op::OH * Conv2Op::OW};
         DenseOp A{(const bf16_t*)dy, 64, B.rows};
-        return launch<64, 64, 2, 2, true, true>(A, B, 64, Conv2Op::K, B.rows, splits, make_epi(dw, Conv2Op::K, nullptr, nullptr, 0, 1.0f, fl), s);
+        return launch<64, 64, 128, 2, 2, true, true, 2>(A, B, 64, Conv2Op::K, B.rows, splits, make_epi(dw, Conv2Op::K, nullptr, nullptr, 0, 1.0f, fl), s);
     } else if (layer == 3) {
         Conv3Op B{x, frame_off, frames * Conv3Op::OH * Conv3Op::OW};
         DenseOp A{(const bf16_t*)dy, 64, B.rows};
-        return launch<64, 64, 2, 2, true, true>(A, B, 64, Conv3Op::K, B.rows, splits, make_epi(dw, Conv3Op::K, nullptr, nullptr, 0, 1.0f, fl), s);
+        return launch<64, 64, 128, 2, 2, true, true, 2>(A, B, 64, Conv3Op::K, B.rows, splits, make_epi(dw, Conv3Op::K, nullptr, nullptr, 0, 1.0f, fl), s);
     }
     return -1;
 }
@@ -385,11 +521,11 @@ DRL_API int drl_conv_dcol(int layer, const void* dy, int frames, const void* w, 
     if (layer == 2) {
         const int M = frames * Conv2Op::OH * Conv2Op::OW;
         DenseOp A{(const bf16_t*)dy, 64, M}, B{(const bf16_t*)w, Conv2Op::K, 64};
-        return launch<128, 64, 2, 2, false, true>(A, B, M, Conv2Op::K, 64, 1, make_epi(dcol, Conv2Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
+        return launch<128, 64, 64, 2, 2, false, true, 2>(A, B, M, Conv2Op::K, 64, 1, make_epi(dcol, Conv2Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
     } else if (layer == 3) {
         const int M = frames * Conv3Op::OH * Conv3Op::OW;
         DenseOp A{(const bf16_t*)dy, 64, M}, B{(const bf16_t*)w, Conv3Op::K, 64};
-        return launch<128, 64, 2, 2, false, true>(A, B, M, Conv3Op::K, 64, 1, make_epi(dcol, Conv3Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
+        return launch<128, 64, 64, 2, 2, false, true, 2>(A, B, M, Conv3Op::K, 64, 1, make_epi(dcol, Conv3Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
     }
     return -1;
 }
@@ -402,5 +538,5 @@ DRL_API int drl_lstm_step(const void* h_prev, const void* w_hh, const float* xg,
     Epilogue ep = make_epi(nullptr, 0, nullptr, nullptr, 0, 1.0f, EPI_LSTM);
     ep.xg = xg; ep.ldxg = 4LL * H; ep.c_prev = c_prev; ep.c_out = c_out; ep.h_out = (bf16_t*)h_out; ep.gates_out = (bf16_t*)gates_out;
     DenseOp A{(const bf16_t*)h_prev, H, M}, B{(const bf16_t*)w_hh, H, 4 * H};
-    return launch<64, 64, 2, 2, false, false>(A, B, M, 4 * H, H, 1, ep, s);
+    return launch<64, 64, 256, 2, 2, false, false, 2>(A, B, M, 4 * H, H, 1, ep, s);
 }

@@ -14,6 +14,8 @@ from .. import native
 
 EPI_RELU, EPI_OUT_F32, EPI_ATOMIC, EPI_MASK = 1, 2, 4, 8
 NT, NN, TN = 0, 1, 2
+# tile variants of drl_gemm: 0 = 64x64x64 | 1 = 128x128x64 | 2 = 64x64x128 | 3 = 64x64x256 | 4 = 128x64x128
+GEMM_SMALL_VARIANT = 0
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -210,8 +212,9 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
     ldc = c.shape[-1] if ldc is None else ldc
     if big is None:
         big = (N % 128 == 0) and (M >= 2048) and (mode != TN or M % 128 == 0)
+    variant = int(big) if not isinstance(big, bool) else (1 if big else GEMM_SMALL_VARIANT)
     ldm = mask.shape[-1] if mask is not None else 0
-    _ck(native.hip().drl_gemm(mode, 1 if big else 0, _p(a), lda, _p(b), ldb, M, N, K, _p(c), ldc, _p(bias), _p(mask), ldm,
+    _ck(native.hip().drl_gemm(mode, variant, _p(a), lda, _p(b), ldb, M, N, K, _p(c), ldc, _p(bias), _p(mask), ldm,
                               scale, flags, splits, _s()), "gemm")
 
 

@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark at the Ape-X (B=512) / R2D2 (T*B=7680) shapes: HIP-event timing of every hot
+kernel in isolation, with achieved TFLOP/s and GB/s. Use it under rocprofv3 --pmc to collect counters for one
+kernel family:   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU ... -- python scripts/kbench.py --only conv1_fwd
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_rl_amd.ops import hip as H  # noqa: E402
+
+DEV = "cuda"
+
+
+def bf(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16)
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps     # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    F = args.frames
+    B = F // 2
+    cases = {}
+    x = torch.randint(0, 256, (F, 84, 84, 4), dtype=torch.uint8, device=DEV)
+    w1, b1 = bf(32, 8, 8, 4, scale=0.05), torch.randn(32, device=DEV)
+    w2, b2 = bf(64, 4, 4, 32, scale=0.05), torch.randn(64, device=DEV)
+    w3, b3 = bf(64, 3, 3, 64, scale=0.05), torch.randn(64, device=DEV)
+    a1 = torch.zeros(F, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    a2 = torch.zeros(F, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
+    a3 = torch.zeros(F, 3136, dtype=torch.bfloat16, device=DEV)
+    wfc, bfc = bf(1024, 3136, scale=0.02), torch.randn(1024, device=DEV)
+    h = torch.zeros(F, 1024, dtype=torch.bfloat16, device=DEV)
+    H.conv_fwd(1, x, w1, b1, a1, F)
+    H.conv_fwd(2, a1, w2, b2, a2, F)
+    H.conv_fwd(3, a2, w3, b3, a3, F)
+    cases["conv1_fwd"] = (lambda: H.conv_fwd(1, x, w1, b1, a1, F), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
+    cases["conv2_fwd"] = (lambda: H.conv_fwd(2, a1, w2, b2, a2, F), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
+    cases["conv3_fwd"] = (lambda: H.conv_fwd(3, a2, w3, b3, a3, F), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
+    for v in (0, 2, 3):
+        cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
+    dh = bf(B, 1024, scale=0.01)
+    gfc = torch.zeros(1024, 3136, device=DEV)
+    d3 = torch.zeros(B, 3136, dtype=torch.bfloat16, device=DEV)
+    for v in (0, 2, 3):
+        cases["fc1_dw_tn_v%d" % v] = (lambda v=v: H.gemm(H.TN, dh, a3[:B], gfc, 1024, 3136, B, flags=H.EPI_OUT_F32, big=v), 2 * B * 1024 * 3136, 4 * 1024 * 3136)
+        cases["fc1_dx_nn_v%d" % v] = (lambda v=v: H.gemm(H.NN, dh, wfc, d3, B, 3136, 1024, mask=a3[:B], flags=H.EPI_MASK, big=v), 2 * B * 1024 * 3136, 2 * 1024 * 3136)
+    d3v = bf(B * 49, 64, scale=0.01)
+    d2v = bf(B * 81, 64, scale=0.01)
+    d1v = bf(B * 400, 32, scale=0.01)
+    g3, g2, g1 = torch.zeros(64, 576, device=DEV), torch.zeros(64, 512, device=DEV), torch.zeros(32, 256, device=DEV)
+    for sp in (16, 32, 64):
+        cases["conv3_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(3, a2[:B], d3v, g3, B, splits=sp), 2 * B * 49 * 64 * 576, B * 10368)
+        cases["conv2_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(2, a1[:B], d2v, g2, B, splits=sp), 2 * B * 81 * 64 * 512, B * 25600)
+        cases["conv1_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(1, x[:B], d1v, g1, B, splits=2 * sp), 2 * B * 400 * 32 * 256, B * 28224)
+    dc3 = torch.zeros(B * 49, 576, dtype=torch.bfloat16, device=DEV)
+    dc2 = torch.zeros(B * 81, 512, dtype=torch.bfloat16, device=DEV)
+    cases["conv3_dcol"] = (lambda: H.conv_dcol(3, d3v, w3, dc3, B), 2 * B * 49 * 64 * 576, 2 * B * 49 * 576)
+    cases["conv2_dcol"] = (lambda: H.conv_dcol(2, d2v, w2, dc2, B), 2 * B * 81 * 64 * 512, 2 * B * 81 * 512)
+    dx2 = torch.zeros(B, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
+    dx1 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    cases["col2im3"] = (lambda: H.col2im(3, dc3, a2[:B], dx2, B), 0, 2 * B * 49 * 576)
+    cases["col2im2"] = (lambda: H.col2im(2, dc2, a1[:B], dx1, B), 0, 2 * B * 81 * 512)
+    db = torch.zeros(64, device=DEV)
+    cases["colsum_d2"] = (lambda: H.colsum(d2v, db, B * 81, 64), 0, 2 * B * 81 * 64)
+    # R2D2-sized GEMMs
+    N = 7680
+    feat = bf(N, 3136)
+    wih = bf(2048, 3136, scale=0.02)
+    xg = torch.zeros(N, 2048, device=DEV)
+    for v in (1, 4):
+        cases["lstm_igemm_v%d" % v] = (lambda v=v: H.gemm(H.NT, feat, wih, xg, N, 2048, 3136, flags=H.EPI_OUT_F32, big=v), 2 * N * 2048 * 3136, 0)
+    hp, whh = bf(64, 512), bf(2048, 512, scale=0.05)
+    xg_t, c0 = torch.randn(64, 2048, device=DEV), torch.zeros(64, 512, device=DEV)
+    ho, co = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 512, device=DEV)
+    cases["lstm_step"] = (lambda: H.lstm_step(hp, whh, xg_t, c0, ho, co, None), 2 * 64 * 2048 * 512, 0)
+    print("%-18s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
+    for name, (fn, flops, byts) in cases.items():
+        if args.only and args.only not in name:
+            continue
+        us = timeit(fn, args.reps)
+        print("%-18s %10.1f %10.1f %10.1f" % (name, us, flops / us / 1e6, byts / us / 1e3))
+
+
+if __name__ == "__main__":
+    main()

@@ -315,6 +315,29 @@ def test_gemm_tn_splitk(hip, M, N, K, big, splits):
     torch.testing.assert_close(c.cpu(), ref, rtol=2e-3, atol=2e-3 * (K ** 0.5) * 0.01 + 1e-3)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+def test_gemm_tile_variants(hip, variant, mode):
+    """Every tile variant (BMxBNxBK / ring depth) on a ragged-K, ragged-M problem incl. split-K atomics."""
+    H = hip
+    M, N, K = (256, 384, 1000) if mode == "TN" else (300, 384, 1000 if mode == "NN" else 1096)
+    if mode == "NT":
+        a, b = _rnd(M, K, seed=1), _rnd(N, K, seed=2, scale=0.05)
+        ref = a.float() @ b.float().t()
+    elif mode == "NN":
+        a, b = _rnd(M, K, seed=3), _rnd(K, N, seed=4, scale=0.05)
+        ref = a.float() @ b.float()
+    else:
+        a, b = _rnd(K, M, seed=5, scale=0.2), _rnd(K, N, seed=6, scale=0.2)
+        ref = a.float().t() @ b.float()
+    c = torch.zeros(M, N, device=DEV)
+    H.gemm(getattr(H, mode), a.to(DEV), b.to(DEV), c, M, N, K, flags=H.EPI_OUT_F32, big=variant)
+    torch.testing.assert_close(c.cpu(), ref, rtol=3e-3, atol=3e-2)
+    c.zero_()
+    H.gemm(getattr(H, mode), a.to(DEV), b.to(DEV), c, M, N, K, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=3, big=variant)
+    torch.testing.assert_close(c.cpu(), ref, rtol=3e-3, atol=3e-2)
+
+
 # ---- conv ----------------------------------------------------------------------------------------------
 LAYERS = {1: (4, 32, 8, 4, 84), 2: (32, 64, 4, 2, 20), 3: (64, 64, 3, 1, 9)}
 
