@@ -14,15 +14,14 @@ typedef unsigned short bf16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even f32 -> bf16 (NaN stays NaN: quiet bit forced)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even f32 -> bf16 in hardware: gfx950 has v_cvt_pk_bf16_f32 (two conversions per instruction)
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const hw_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hw_bf16x2));
 }
-
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -52,23 +52,36 @@ __global__ __launch_bounds__(256) void k_col2im(const bf16_t* __restrict__ dcol,
     }
 }
 
-// db[n] += sum_m dY[m][n]; grid = (N/CW, ceil(M/RPB)), block = 256 (256/CW row phases x CW columns)
-#define COLSUM_RPB 128
-template <int CW>
-__global__ __launch_bounds__(256) void k_colsum(const bf16_t* __restrict__ dy, int M, int N, float* __restrict__ db) {
-    constexpr int PH = 256 / CW;
-    __shared__ float red[PH][CW];
-    const int c = threadIdx.x % CW, col = blockIdx.x * CW + c, ph = threadIdx.x / CW;
-    const int r0 = blockIdx.y * COLSUM_RPB, r1 = min(M, r0 + COLSUM_RPB);
-    float acc = 0.f;
-    for (int r = r0 + ph; r < r1; r += PH) acc += bf2f(dy[(long long)r * N + col]);
-    red[ph][c] = acc;
-    __syncthreads();
-    if (ph == 0) {
-        float s = 0.f;
+// db[n] += sum_m dY[m][n]. The matrix is walked as a flat stream of 16-B chunks (8 bf16 columns): with N/8 dividing
+// 256 every thread stays on the same 8 columns, so it accumulates 8 floats in registers over its whole slice, the
+// block folds its 256 partial rows through LDS and issues N atomics. grid = ceil(chunks / cpb), block = 256.
+__global__ __launch_bounds__(256) void k_colsum(const bf16_t* __restrict__ dy, long long total, int NC8, int cpb,
+                                               float* __restrict__ db) {
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x;
+    const long long c0 = (long long)blockIdx.x * cpb, c1 = min(total, c0 + cpb);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](const uint4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < PH; ++i) s += red[i][c];
-        atomicAdd(&db[col], s);
+        for (int t = 0; t < 4; ++t) { acc[2 * t] += __uint_as_float(w[t] << 16); acc[2 * t + 1] += __uint_as_float(w[t] & 0xffff0000u); }
+    };
+    long long i = c0 + tid;
+    for (; i + 768 < c1; i += 1024) {          // 4 independent 16-B loads in flight per thread
+        const uint4 v0 = reinterpret_cast<const uint4*>(dy)[i], v1 = reinterpret_cast<const uint4*>(dy)[i + 256];
+        const uint4 v2 = reinterpret_cast<const uint4*>(dy)[i + 512], v3 = reinterpret_cast<const uint4*>(dy)[i + 768];
+        add(v0); add(v1); add(v2); add(v3);
+    }
+    for (; i < c1; i += 256) add(reinterpret_cast<const uint4*>(dy)[i]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[tid][t] = acc[t];
+    __syncthreads();
+    const int N = NC8 * 8, reps = 256 / NC8;
+    for (int col = tid; col < N; col += 256) {
+        const int g = col >> 3, e = col & 7;
+        float sum = 0.f;
+        for (int j = 0; j < reps; ++j) sum += red[j * NC8 + g][e];
+        atomicAdd(&db[col], sum);
     }
 }
 
@@ -107,9 +120,13 @@ DRL_API int drl_col2im(int layer, const void* dcol, const void* act_in, void* dx
 }
 
 DRL_API int drl_colsum(const void* dy, int M, int N, float* db, hipStream_t s) {
-    if (M <= 0 || N <= 0 || N % 32 != 0) return -1;
-    if (N % 64 == 0) k_colsum<64><<<dim3(N / 64, (M + COLSUM_RPB - 1) / COLSUM_RPB), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
-    else k_colsum<32><<<dim3(N / 32, (M + COLSUM_RPB - 1) / COLSUM_RPB), 256, 0, s>>>((const bf16_t*)dy, M, N, db);
+    if (M <= 0 || N < 8 || N > 2048 || (N & (N - 1))) return -1;   // N/8 must divide 256
+    const long long total = (long long)M * (N / 8);
+    // few blocks on purpose: same-address fp32 atomics serialise in L2 (~35 ns each on MI355X), so the number of
+    // blocks, not the bytes read, sets the time of this kernel
+    long long cpb = ((total + 127) / 128 + 255) / 256 * 256;
+    if (cpb < 1024) cpb = 1024;
+    k_colsum<<<(unsigned)((total + cpb - 1) / cpb), 256, 0, s>>>((const bf16_t*)dy, total, N / 8, (int)cpb, db);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,266 @@
+// Direct (barrier-free) forward convolutions for the Nature-CNN torso on gfx950 (forward).
+//
+// The K ordering (kh, kw, c) of the NHWC implicit GEMM has a property the generic LDS-tiled kernel in gemm.hip does not
+// use: one MFMA k-step (32 contraction elements) is a CONTIGUOUS run of the input —
+//     conv1: one patch row  = 8 px x 4 ch u8   = 32 bytes,
+//     conv2: one patch pixel = 32 ch bf16       = 64 bytes,
+//     conv3: half a patch pixel (64 ch bf16)    = 64 bytes,
+// and the 8 consecutive k a lane needs for its 16x16x32 operand fragment are one 8-byte (u8) / 16-byte (bf16) global
+// load. So the activation operand goes global -> VGPR directly in MFMA fragment layout: no LDS staging, no
+// __syncthreads, no shared K-loop between waves. Every wave walks its own run of 16- or 32-row output tiles with the
+// next tile's loads in flight, and the weights are resident for the life of the wave:
+//     conv1: all 32x256 weights live in 64 VGPRs per lane;
+//     conv2/3: 64x512 / 64x576 weights are copied once per workgroup into LDS in fragment order (conflict-free
+//              ds_read_b128), then only read.
+// Operands are passed swapped (acc = mfma(W, X)) so a lane ends up with 4 consecutive output channels of one output
+// pixel: bias + ReLU + v_cvt_pk_bf16_f32 and an 8-byte store.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+// 8 u8 -> 8 bf16 (exact): v_cvt_f32_ubyteN, then one v_perm_b32 per pair keeps the two high halves
+__device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
+    uint32_t o[4];
+    const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = w[i >> 1];
+        const float f0 = (i & 1) ? (float)((s >> 16) & 0xffu) : (float)(s & 0xffu);     // -> v_cvt_f32_ubyte{2,0}
+        const float f1 = (i & 1) ? (float)(s >> 24) : (float)((s >> 8) & 0xffu);          // -> v_cvt_f32_ubyte{3,1}
+        o[i] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+    }
+    return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv1: u8 [*,84,84,4] (dense batch, or frames of a replay store addressed by byte offsets) -> bf16 [n,20,20,32]
+// ---------------------------------------------------------------------------------------------------------------
+template <bool OFF>
+__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, const long long* __restrict__ frame_off,
+                                                     const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                     bf16_t* __restrict__ out, int M, int per) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int ntiles = (M + 15) >> 4;
+    // every wave owns `per` CONSECUTIVE 16-row tiles (neighbouring output pixels overlap in the input: L1/L2 hits)
+    const int t0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
+    if (t0 >= ntiles) return;                       // wave-uniform: no barriers in this kernel
+    bf16x8 wf[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            wf[t][s] = *reinterpret_cast<const bf16x8*>(w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8);
+    // MFMA row i of weight tile t is output channel (i/4)*8 + t*4 + i%4 (a free permutation of the weight rows): the
+    // lane that ends up with accumulator rows g*4..g*4+3 of both tiles then owns the 8 CONSECUTIVE channels g*8..g*8+7
+    // of its pixel: one 16-byte store per lane, 1 KB contiguous per wave and tile.
+    float4 b4[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
+
+    // Byte offset of this lane's first fragment (patch row 0) in tile `tile` = frame base + pixel offset; rows past M
+    // re-read row M-1. The frame base of a replay-store frame is itself a (dependent) global load: it is issued two
+    // tiles ahead and BEFORE the data loads of the next tile, so waiting for it (in-order vmcnt) never drains the
+    // data prefetch.
+    auto locate = [&](int tile, int& b) -> int {
+        const int m = min(min(tile, ntiles - 1) * 16 + r, M - 1);
+        b = m / 400;
+        const int rem = m - b * 400, oy = rem / 20, ox = rem - oy * 20;
+        return oy * (4 * 336) + ox * 16 + g * 8;
+    };
+    auto frame_base = [&](int b) -> long long {
+        if constexpr (OFF) return frame_off[b];
+        else return (long long)b * 28224;
+    };
+    uint2 bufa[8], bufb[8];
+    int b0, b1;
+    const int p0 = locate(t0, b0), p1 = locate(t0 + 1, b1);
+    const long long f0 = frame_base(b0);
+    long long fnext = frame_base(b1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bufa[s] = *reinterpret_cast<const uint2*>(x + f0 + p0 + s * 336);
+    long long bnext = fnext + p1;
+    // one tile: prefetch tile+1 into `nxt`, compute `cur`. Called with the two buffers swapped (no register copies,
+    // and the compiler cannot sink the prefetch below the compute because both buffers are live).
+    auto body = [&](uint2 (&cur)[8], uint2 (&nxt)[8], int tile) __attribute__((always_inline)) {
+        int b2;
+        const int p2 = locate(tile + 2, b2);
+        const long long f2 = frame_base(b2);                                                         // tile + 2 (first)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + s * 336);    // tile + 1
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bf16x8 xf = u8x8_to_bf16(cur[s]);
+            acc[0] = mfma16(wf[0][s], xf, acc[0]);
+            acc[1] = mfma16(wf[1][s], xf, acc[1]);
+        }
+        const int m = tile * 16 + r;
+        if (m < M) {
+            constexpr float SC = 1.0f / 255.0f;          // pixel normalisation x/255 folded into the epilogue
+            uint32_t o[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                o[2 * t] = pack_bf2(fmaxf(acc[t][0] * SC + b4[t].x, 0.f), fmaxf(acc[t][1] * SC + b4[t].y, 0.f));
+                o[2 * t + 1] = pack_bf2(fmaxf(acc[t][2] * SC + b4[t].z, 0.f), fmaxf(acc[t][3] * SC + b4[t].w, 0.f));
+            }
+            *reinterpret_cast<uint4*>(out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        bnext = f2 + p2;
+    };
+    int tile = t0;
+    for (; tile + 1 < t1; tile += 2) {      // no skip path inside the loop: the back edge keeps exact vmcnt counts
+        body(bufa, bufb, tile);
+        body(bufb, bufa, tile + 1);
+    }
+    if (tile < t1) body(bufa, bufb, tile);  // odd tail
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv2 / conv3: bf16 NHWC -> bf16 NHWC, 64 output channels, weights resident in LDS in fragment order.
+// A k-step is 64 contiguous input bytes (C = 32: one patch pixel; C = 64: half a patch pixel). Each wave owns 32-row
+// tiles (2 MFMA row blocks share every weight fragment read from LDS) and runs KS phases (one patch row each) with
+// the next phase's loads in flight.
+// ---------------------------------------------------------------------------------------------------------------
+template <int H, int W, int C, int KS, int S, int RT, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void k_conv_direct(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                            int M, int per) {
+    constexpr int OH = (H - KS) / S + 1, OW = (W - KS) / S + 1, K = KS * KS * C, NS = K / 32;   // NS k-steps
+    constexpr int SPR = KS * C / 32;          // k-steps per patch row (conv2: 4, conv3: 6)
+    constexpr int TR = RT * 16;               // rows per wave tile
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                            // 4 * NS * 1 KB
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    // weights -> LDS, fragment order: frag (t, s) holds for lane l the 8 k of W[t*16 + l%16][s*32 + (l/16)*8 ..]
+    for (int i = tid; i < 4 * NS * 64; i += NWV * 64) {
+        const int l = i & 63, f = i >> 6, s = f % NS, t = f / NS;
+        *reinterpret_cast<uint4*>(smem + (size_t)i * 16) =
+            *reinterpret_cast<const uint4*>(w + (size_t)(t * 16 + (l & 15)) * K + s * 32 + (l >> 4) * 8);
+    }
+    __syncthreads();                          // the only barrier: weights are read-only from here on
+    const int ntiles = (M + TR - 1) / TR;
+    // every wave owns `per` CONSECUTIVE tiles: neighbouring output pixels share input pixels, so the re-reads hit L1/L2
+    const int t0 = (blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(tid >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
+    float4 b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + t * 16 + g * 4);
+
+    // element offset of patch (row m) origin + this lane's 8-channel group
+    auto base_of = [&](int tile, int sub) -> unsigned {
+        const int m = min(min(tile, ntiles - 1) * TR + sub * 16 + r, M - 1);
+        const int b = m / (OH * OW), rem = m - b * (OH * OW), oy = rem / OW, ox = rem - oy * OW;
+        return (unsigned)(((b * H + oy * S) * W + ox * S) * C + g * 8);
+    };
+    auto load_row = [&](uint4 (&dst)[RT][SPR], const unsigned (&base)[RT], int ky) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+#pragma unroll
+            for (int j = 0; j < SPR; ++j) dst[u][j] = *reinterpret_cast<const uint4*>(x + base[u] + ky * (W * C) + j * 32);
+    };
+    unsigned base[RT], nbase[RT];
+#pragma unroll
+    for (int u = 0; u < RT; ++u) base[u] = base_of(t0, u);
+    uint4 cur[RT][SPR], nxt[RT][SPR];
+    load_row(cur, base, 0);
+    for (int tile = t0; tile < t1; ++tile) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) nbase[u] = base_of(tile + 1, u);
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            // compiler fence: the weight fragments are loop-invariant LDS reads and LICM would hoist all 4*NS of them
+            // (256+ VGPRs, spills) out of the tile loop; they must be re-read from LDS in every phase
+            asm volatile("" ::: "memory");
+            if (ky + 1 < KS) load_row(nxt, base, ky + 1);
+            else load_row(nxt, nbase, 0);                         // first patch row of the wave's next tile
+#pragma unroll
+            for (int j = 0; j < SPR; ++j) {
+                const int s = ky * SPR + j;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(t * NS + s) * 64 + lane) * 16);
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) acc[u][t] = mfma16(wf, __builtin_bit_cast(bf16x8, cur[u][j]), acc[u][t]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RT; ++u)
+#pragma unroll
+                for (int j = 0; j < SPR; ++j) cur[u][j] = nxt[u][j];
+        }
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int m = tile * TR + u * 16 + r;
+            if (m < M) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t lo = pack_bf2(fmaxf(acc[u][t][0] + b4[t].x, 0.f), fmaxf(acc[u][t][1] + b4[t].y, 0.f));
+                    const uint32_t hi = pack_bf2(fmaxf(acc[u][t][2] + b4[t].z, 0.f), fmaxf(acc[u][t][3] + b4[t].w, 0.f));
+                    *reinterpret_cast<uint2*>(out + (long long)m * 64 + t * 16 + g * 4) = make_uint2(lo, hi);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RT; ++u) base[u] = nbase[u];
+    }
+}
+
+// tiles per wave so that at most `slots` waves are needed; returns the grid in *grid
+static int plan(int ntiles, int slots, int nwv, int* grid) {
+    int per = (ntiles + slots - 1) / slots;
+    if (per < 1) per = 1;
+    *grid = (ntiles + per * nwv - 1) / (per * nwv);
+    return per;
+}
+
+template <int H, int W, int C, int KS, int S, int RT, int NWV>
+static void launch_direct(const void* x, const void* w, const float* bias, void* out, int M, hipStream_t s) {
+    constexpr int LDS = 4 * (KS * KS * C / 32) * 1024;
+    auto kern = k_conv_direct<H, W, C, KS, S, RT, NWV>;
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+    (void)once;
+    int grid;
+    const int per = plan((M + RT * 16 - 1) / (RT * 16), 256 * 2 * NWV, NWV, &grid);   // 2 workgroups resident per CU
+    kern<<<grid, NWV * 64, LDS, s>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
+}
+
+// layer 1: x u8 (+ optional per-frame byte offsets) ; layers 2/3: x bf16 NHWC. out bf16 NHWC, bias + ReLU fused.
+// variant (layers 2/3): 0 = 32-row tiles, 4 waves | 1 = 16-row tiles, 8 waves | 2 = 32-row, 8 waves | 3 = 16-row, 4 waves
+DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const float* bias, void* out, int frames,
+                                const long long* frame_off, int variant, hipStream_t s) {
+    if (frames <= 0) return -1;
+    if (layer == 1) {
+        const int M = frames * 400;
+        int grid;
+        const int per = plan((M + 15) / 16, 256 * 16, 4, &grid);
+        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
+        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, nullptr, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
+    } else if (layer == 2) {
+        if ((long long)frames * 20 * 20 * 32 >= (1LL << 32)) return -8;
+        const int M = frames * 81;
+        switch (variant) {
+            case 0: launch_direct<20, 20, 32, 4, 2, 2, 4>(x, w, bias, out, M, s); break;
+            case 1: launch_direct<20, 20, 32, 4, 2, 1, 8>(x, w, bias, out, M, s); break;
+            case 2: launch_direct<20, 20, 32, 4, 2, 2, 8>(x, w, bias, out, M, s); break;
+            default: launch_direct<20, 20, 32, 4, 2, 1, 4>(x, w, bias, out, M, s); break;
+        }
+    } else if (layer == 3) {
+        if ((long long)frames * 9 * 9 * 64 >= (1LL << 32)) return -8;
+        const int M = frames * 49;
+        switch (variant) {
+            case 0: launch_direct<9, 9, 64, 3, 1, 2, 4>(x, w, bias, out, M, s); break;
+            case 1: launch_direct<9, 9, 64, 3, 1, 1, 8>(x, w, bias, out, M, s); break;
+            case 2: launch_direct<9, 9, 64, 3, 1, 2, 8>(x, w, bias, out, M, s); break;
+            default: launch_direct<9, 9, 64, 3, 1, 1, 4>(x, w, bias, out, M, s); break;
+        }
+    } else return -1;
+    return (int)hipGetLastError();
+}

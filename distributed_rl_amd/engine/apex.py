@@ -55,7 +55,8 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 class ApexEngine:
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
-                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 96):
+                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
+                 overlap: bool = True):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -90,6 +91,11 @@ class ApexEngine:
         self.wgrad_splits = wgrad_splits
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
+        # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
+        # (online forward -> TD -> dgrad chain) and every kernel alone is too small to fill 256 CUs, so they are
+        # forked onto side streams (captured as parallel branches of the hipGraph)
+        self.overlap = overlap
+        self.side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if overlap else []
         self._graphs = None
         self.steps_done = 0
 
@@ -98,33 +104,53 @@ class ApexEngine:
         self.T.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
 
+    def _fork(self, i: int):
+        """Context manager: run the body on side stream i after everything issued so far on the main stream."""
+        import contextlib
+        if not self.overlap:
+            return contextlib.nullcontext()
+        side = self.side[i]
+        side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(side)
+
+    def _join(self) -> None:
+        for side in self.side:
+            torch.cuda.current_stream().wait_stream(side)
+
     def _forward_backward(self) -> None:
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
         H.step_begin(self.st, r.n_items)
         r.sample(self.st)
         self.G.flat.zero_()
+        with self._fork(0):                                        # target net on s' || online net on [s ; s']
+            torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
         torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
-        torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
+        self._join()
         H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
                   cfg.prio_eps, self.dq, self.new_prio, n_scale=1.0)
         G, Pb, on = self.G, self.Pb, self.on
         h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
+        sp = self.wgrad_splits
         H.head_bwd(self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
                    G.view("val2.w"), G.view("val2.b"))
-        H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
-        H.colsum(self.dh, G.view("fc1.b"), B, 1024)
+        with self._fork(0):                                        # fc1 dW, db || fc1 dX
+            H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
+            H.colsum(self.dh, G.view("fc1.b"), B, 1024)
         H.gemm(H.NN, self.dh, Pb.view("fc1.w"), self.d3.view(B, 3136), B, 3136, 1024, mask=a3, flags=H.EPI_MASK, big=False)
-        sp = self.wgrad_splits
-        H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
-        H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
+        with self._fork(1):                                        # conv3 dW, db || conv3 dX
+            H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
+            H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
         H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, B)
         H.col2im(3, self.dcol3, a2, self.d2, B)
-        H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), B, splits=sp)
-        H.colsum(self.d2, G.view("conv2.b"), B * 81, 64)
+        with self._fork(0):                                        # conv2 dW, db || conv2 dX
+            H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), B, splits=sp)
+            H.colsum(self.d2, G.view("conv2.b"), B * 81, 64)
         H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, B)
         H.col2im(2, self.dcol2, a1, self.d1, B)
-        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), B, frame_off=r.frame_off, splits=2 * sp)
-        H.colsum(self.d1, G.view("conv1.b"), B * 400, 32)
+        with self._fork(1):
+            H.colsum(self.d1, G.view("conv1.b"), B * 400, 32)
+        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), B, frame_off=r.frame_off, splits=4 * sp)
+        self._join()
 
     def _optimize(self) -> None:
         cfg = self.cfg

@@ -30,6 +30,8 @@ SIGS = {
     "drl_gemm": [I, I, P, L, P, L, I, I, I, P, L, P, P, L, F, I, I, P],
     "drl_conv_fwd": [I, P, P, I, P, P, P, I, P],
     "drl_conv_wgrad": [I, P, P, I, P, P, I, P],
+    # conv_direct.hip
+    "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm.hip

@@ -218,10 +218,18 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
                               scale, flags, splits, _s()), "gemm")
 
 
+CONV_FWD_DIRECT = True   # barrier-free direct kernels (conv_direct.hip); False = LDS-tiled implicit GEMM (gemm.hip)
+
+
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
-             frame_off: Optional[torch.Tensor] = None, relu: bool = True) -> None:
+             frame_off: Optional[torch.Tensor] = None, relu: bool = True, direct: Optional[bool] = None,
+             variant: int = 0) -> None:
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
     _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
+    if (CONV_FWD_DIRECT if direct is None else direct) and relu:
+        _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
+            "conv_fwd_direct")
+        return
     _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out), 1 if relu else 0, _s()),
         "conv_fwd")
 

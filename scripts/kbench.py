@@ -19,14 +19,38 @@ def bf(*shape, scale=1.0):
     return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16)
 
 
+EAGER = False
+
+
 def timeit(fn, reps=20, warm=3):
-    for _ in range(warm):
-        fn()
+    """`reps` back-to-back launches captured in one hipGraph (no host launch overhead in the number)."""
+    if EAGER:                      # plain launches (for rocprofv3 --pmc runs: counters are attributed per dispatch)
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e3 / reps
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / reps     # us
@@ -37,7 +61,10 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--eager", action="store_true")
     args = ap.parse_args()
+    global EAGER
+    EAGER = args.eager
     F = args.frames
     B = F // 2
     cases = {}
@@ -53,11 +80,18 @@ def main():
     H.conv_fwd(1, x, w1, b1, a1, F)
     H.conv_fwd(2, a1, w2, b2, a2, F)
     H.conv_fwd(3, a2, w3, b3, a3, F)
-    cases["conv1_fwd"] = (lambda: H.conv_fwd(1, x, w1, b1, a1, F), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
-    cases["conv2_fwd"] = (lambda: H.conv_fwd(2, a1, w2, b2, a2, F), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
-    cases["conv3_fwd"] = (lambda: H.conv_fwd(3, a2, w3, b3, a3, F), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
+    for d in (-1, 0, 1, 2, 3):
+        sfx = "_direct%d" % d if d >= 0 else "_tiled"
+        if d <= 0:
+            cases["conv1_fwd" + sfx] = (lambda d=d: H.conv_fwd(1, x, w1, b1, a1, F, direct=d >= 0), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
+        cases["conv2_fwd" + sfx] = (lambda d=d: H.conv_fwd(2, a1, w2, b2, a2, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
+        cases["conv3_fwd" + sfx] = (lambda d=d: H.conv_fwd(3, a2, w3, b3, a3, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
     for v in (0, 2, 3):
         cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
+    hf = torch.zeros(F, 1024, device=DEV)
+    for sp in (2, 4, 8):
+        cases["fc1_fwd_v1_sk%d" % sp] = (lambda sp=sp: H.gemm(H.NT, a3, wfc, hf, F, 1024, 3136, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=sp, big=1), 2 * F * 1024 * 3136, 0)
+        cases["fc1_fwd_v4_sk%d" % sp] = (lambda sp=sp: H.gemm(H.NT, a3, wfc, hf, F, 1024, 3136, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=sp, big=4), 2 * F * 1024 * 3136, 0)
     dh = bf(B, 1024, scale=0.01)
     gfc = torch.zeros(1024, 3136, device=DEV)
     d3 = torch.zeros(B, 3136, dtype=torch.bfloat16, device=DEV)
@@ -82,6 +116,9 @@ def main():
     cases["col2im2"] = (lambda: H.col2im(2, dc2, a1[:B], dx1, B), 0, 2 * B * 81 * 512)
     db = torch.zeros(64, device=DEV)
     cases["colsum_d2"] = (lambda: H.colsum(d2v, db, B * 81, 64), 0, 2 * B * 81 * 64)
+    cases["colsum_d1"] = (lambda: H.colsum(d1v, db, B * 400, 32), 0, 2 * B * 400 * 32)
+    dbh = torch.zeros(1024, device=DEV)
+    cases["colsum_dh"] = (lambda: H.colsum(dh, dbh, B, 1024), 0, 2 * B * 1024)
     # R2D2-sized GEMMs
     N = 7680
     feat = bf(N, 3136)

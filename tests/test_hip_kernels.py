@@ -357,13 +357,14 @@ def _conv_setup(layer, frames, seed):
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
-@pytest.mark.parametrize("frames", [1, 7, 96])
-def test_conv_fwd(hip, layer, frames):
+@pytest.mark.parametrize("frames", [1, 7, 96, 700])
+@pytest.mark.parametrize("direct", [-1, 0, 1, 2, 3])
+def test_conv_fwd(hip, layer, frames, direct):
     H = hip
     x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 100 + frames)
     oh = (hw - ks) // s + 1
     out = torch.zeros(frames, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
-    H.conv_fwd(layer, x.to(DEV), w.to(DEV), bias.to(DEV), out, frames)
+    H.conv_fwd(layer, x.to(DEV), w.to(DEV), bias.to(DEV), out, frames, direct=direct >= 0, variant=max(direct, 0))
     ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=s)).permute(0, 2, 3, 1)
     torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
@@ -374,10 +375,12 @@ def test_conv1_frame_offsets(hip):
     pick = torch.tensor([7, 3, 19, 7, 0])
     _, _, w, bias, _ = _conv_setup(1, 1, 5)
     out = torch.zeros(5, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
-    H.conv_fwd(1, store.to(DEV), w.to(DEV), bias.to(DEV), out, 5, frame_off=(pick * 28224).to(DEV))
-    ref = torch.zeros_like(out)
-    H.conv_fwd(1, store[pick].contiguous().to(DEV), w.to(DEV), bias.to(DEV), ref, 5)
-    assert torch.equal(out, ref)
+    for direct in (False, True):
+        out.zero_()
+        H.conv_fwd(1, store.to(DEV), w.to(DEV), bias.to(DEV), out, 5, frame_off=(pick * 28224).to(DEV), direct=direct)
+        ref = torch.zeros_like(out)
+        H.conv_fwd(1, store[pick].contiguous().to(DEV), w.to(DEV), bias.to(DEV), ref, 5, direct=direct)
+        assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
@@ -399,6 +402,17 @@ def test_conv_wgrad_and_bias(hip, layer, frames, splits):
     db = torch.zeros(cout, device=DEV)
     H.colsum(dy.to(DEV), db, frames * oh * oh, cout)
     torch.testing.assert_close(db.cpu(), bf_.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N", [(5, 32), (204800, 32), (25088, 64), (512, 1024), (333, 2048), (1, 8)])
+def test_colsum_shapes(hip, M, N):
+    H = hip
+    g = torch.Generator().manual_seed(M + N)
+    dy = bf(torch.randn(M, N, generator=g))
+    db = torch.full((N,), 0.5, device=DEV)              # accumulates on top of what is there
+    H.colsum(dy.to(DEV), db, M, N)
+    ref = dy.double().sum(0).float() + 0.5
+    torch.testing.assert_close(db.cpu(), ref, rtol=1e-3, atol=1e-3 * max(1.0, M ** 0.5))
 
 
 @pytest.mark.parametrize("layer", [2, 3])
