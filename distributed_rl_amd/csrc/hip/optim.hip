@@ -36,10 +36,11 @@ __device__ __forceinline__ float clip_coef_from_partials(const float* __restrict
 
 // mode 0: RMSprop (alpha, eps; no momentum, not centered).  mode 1: Adam (beta1, beta2, eps, bias correction).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
+__global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m1,
                                                  float* __restrict__ m2, bf16_t* __restrict__ p_bf16, long long n,
                                                  const float* __restrict__ partial, int n_partial, float grad_scale,
-                                                 float max_norm, float lr, float a1, float a2, float eps, StepState* st) {
+                                                 float max_norm, float lr, float a1, float a2, float eps, StepState* st,
+                                                 int zero_grad) {
     __shared__ float red[32];
     float norm;
     const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm) * grad_scale;
@@ -52,12 +53,15 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, const f
     }
     const long long n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
-    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* g4 = reinterpret_cast<float4*>(g);
     float4* m14 = reinterpret_cast<float4*>(m1);
     float4* m24 = reinterpret_cast<float4*>(m2);
     uint2* pb4 = reinterpret_cast<uint2*>(p_bf16);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pv = p4[i], gv = g4[i];
+        // the split-K / bias-gradient kernels of the NEXT step accumulate with atomics: hand them a zeroed buffer from
+        // this pass (the line is in flight anyway) instead of a separate memset launch
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
         if (MODE == 0) {
             float4 sv = m14[i];
@@ -111,21 +115,21 @@ DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART 
     return (int)hipGetLastError();
 }
 
-DRL_API int drl_rmsprop_step(float* p, const float* g, float* sq, void* p_bf16, long long n, const float* partial,
+DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long long n, const float* partial,
                              int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
-                             hipStream_t s) {
+                             int zero_grad, hipStream_t s) {
     if (n <= 0 || (n & 3)) return -1;
     k_opt_step<0><<<grid_for(n), 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
-                                              lr, alpha, 0.f, eps, (StepState*)st);
+                                              lr, alpha, 0.f, eps, (StepState*)st, zero_grad);
     return (int)hipGetLastError();
 }
 
-DRL_API int drl_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const float* partial,
+DRL_API int drl_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, const float* partial,
                           int n_partial, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
-                          void* st, hipStream_t s) {
+                          void* st, int zero_grad, hipStream_t s) {
     if (n <= 0 || (n & 3) || !st) return -1;
     k_opt_step<1><<<grid_for(n), 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
-                                              beta1, beta2, eps, (StepState*)st);
+                                              beta1, beta2, eps, (StepState*)st, zero_grad);
     return (int)hipGetLastError();
 }
 

@@ -41,12 +41,23 @@ __global__ void k_step_end(StepState* st) {
 __global__ __launch_bounds__(256) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
                                                int* __restrict__ idx_out, float* __restrict__ prio_out,
                                                const int* __restrict__ gen, int* __restrict__ gen_out,
-                                               long long* __restrict__ frame_off, long long frame_bytes) {
+                                               long long* __restrict__ frame_off, long long frame_bytes,
+                                               const long long* __restrict__ begin_n_items) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;   // whole wave exits together
     Philox ph(seed);
-    const unsigned long long ctr = st->rng_ctr;
+    // fused step_begin (learner engines): the Philox counter of step t is rng_ctr + t + 1 (nobody writes rng_ctr or step
+    // while this kernel runs), and wave 0 publishes beta / n_items for the kernels that follow
+    unsigned long long ctr = st->rng_ctr;
+    if (begin_n_items) {
+        const unsigned long long t = st->step;
+        ctr += t + 1;
+        if (b == 0 && lane == 0) {
+            st->beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
+            st->n_items = *begin_n_items;
+        }
+    }
     uint4 r = ph(ctr, (unsigned long long)b);
     uint32_t rnd[4] = {r.x, r.y, r.z, r.w};
     long long node = 0;
@@ -103,6 +114,80 @@ __global__ __launch_bounds__(256) void k_fix_level(TreeDesc tr, int level, const
     if (lane == 0) tr.base[tr.off[level] + node] = v;
 }
 
+// ---- fused priority write-back: 2 launches for any tree depth ---------------------------------------------------
+// K1 (one wave per index): leaves + level 1. A wave applies EVERY batch entry that falls into its level-1 node (it
+// scans the index list), so the 64 children it sums are final no matter which other waves run when: no inter-block
+// dependency, duplicates resolve to the entry with the highest batch position (deterministic), all waves of a node
+// write identical values.
+__global__ __launch_bounds__(256) void k_update_l01(TreeDesc tr, const int* __restrict__ idx, const float* __restrict__ val,
+                                                   int n, const int* __restrict__ gen, const int* __restrict__ gen_expected) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int s = idx[i];
+    if (s < 0 || s >= tr.cap) return;
+    if (gen && gen_expected && gen[s] != gen_expected[i]) return;
+    const long long node = (long long)s >> 6;
+    float v = tr.base[tr.off[0] + node * 64 + lane];
+    for (int c = 0; c < n; c += 64) {
+        const int j = c + lane;
+        int sj = -1;
+        if (j < n) {
+            sj = idx[j];
+            if (sj < 0 || sj >= tr.cap || ((long long)sj >> 6) != node) sj = -1;
+            else if (gen && gen_expected && gen[sj] != gen_expected[j]) sj = -1;
+        }
+        unsigned long long m = __ballot(sj >= 0);
+        while (m) {
+            const int bpos = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int t = __shfl(sj, bpos, WAVE);
+            const float x = val[c + bpos];
+            if (lane == (t & 63)) v = x;
+        }
+    }
+    tr.base[tr.off[0] + node * 64 + lane] = v;
+    if (tr.n_levels > 1) {
+        const float sum = wave_sum(v);
+        if (lane == 0) tr.base[tr.off[1] + node] = sum;
+    }
+}
+
+// K2: every node of every level >= 2 is rebuilt directly FROM LEVEL 1 (a level-l node covers 64^(l-1) level-1 values),
+// so the levels do not depend on each other and one launch rebuilds them all, exactly (no += delta drift). Level 2:
+// one wave per node; levels >= 3: one block per node. Block 0 optionally ends the step (step += 1).
+__global__ __launch_bounds__(256) void k_rebuild_upper(TreeDesc tr, int n2_blocks, StepState* st_end) {
+    __shared__ float red[17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && st_end) st_end->step += 1;
+    if (tr.n_levels < 3) return;
+    const long long n1 = tr.off[2] - tr.off[1];                    // padded level-1 size (zeros past the live nodes)
+    const float* l1 = tr.base + tr.off[1];
+    if ((int)blockIdx.x < n2_blocks) {
+        const long long node = (long long)blockIdx.x * 4 + wave;
+        const long long n2 = (n1 + 63) / 64;
+        if (node >= n2) return;
+        const long long k = node * 64 + lane;
+        const float v = wave_sum(k < n1 ? l1[k] : 0.f);
+        if (lane == 0) tr.base[tr.off[2] + node] = v;
+        return;
+    }
+    // levels >= 3: find (level, node) of this block
+    long long rest = (long long)blockIdx.x - n2_blocks, span = 64LL * 64;
+    int lvl = 3;
+    for (; lvl < tr.n_levels; ++lvl, span *= 64) {
+        const long long nl = (n1 + span - 1) / span;
+        if (rest < nl) break;
+        rest -= nl;
+    }
+    if (lvl >= tr.n_levels) return;
+    const long long k0 = rest * span, k1 = min(n1, k0 + span);
+    float acc = 0.f;
+    for (long long k = k0 + threadIdx.x; k < k1; k += 256) acc += l1[k];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) tr.base[tr.off[lvl] + rest] = acc;
+}
+
 // Ring ingest: slots [start, start+n) mod cap get new priorities and a new generation.
 __global__ void k_ingest(TreeDesc tr, long long start, int n, const float* __restrict__ prio,
                          int* __restrict__ gen, int* __restrict__ idx_out) {
@@ -147,20 +232,34 @@ DRL_API int drl_step_end(void* st, hipStream_t s) {
 
 DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, long long cap, void* st,
                                unsigned long long seed, int B, int* idx_out, float* prio_out, const int* gen,
-                               int* gen_out, long long* frame_off, long long frame_bytes, hipStream_t s) {
+                               int* gen_out, long long* frame_off, long long frame_bytes, const long long* begin_n_items,
+                               hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || B <= 0) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
-    k_sample<<<(B + 3) / 4, 256, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes);
+    k_sample<<<(B + 3) / 4, 256, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes,
+                                        begin_n_items);
     return (int)hipGetLastError();
+}
+
+static void rebuild_upper(const TreeDesc& d, void* st_end, hipStream_t s) {
+    if (d.n_levels < 3) {
+        if (st_end) k_step_end<<<1, 64, 0, s>>>((StepState*)st_end);
+        return;
+    }
+    const long long n1 = d.off[2] - d.off[1];
+    const int n2_blocks = (int)(((n1 + 63) / 64 + 3) / 4);
+    long long blocks = n2_blocks, span = 64LL * 64;
+    for (int l = 3; l < d.n_levels; ++l, span *= 64) blocks += (n1 + span - 1) / span;
+    k_rebuild_upper<<<(unsigned)blocks, 256, 0, s>>>(d, n2_blocks, (StepState*)st_end);
 }
 
 // set leaves + recompute all ancestor levels
 DRL_API int drl_sumtree_update(float* base, int n_levels, const long long* off, long long cap, const int* idx,
-                               const float* val, int n, const int* gen, const int* gen_expected, hipStream_t s) {
+                               const float* val, int n, const int* gen, const int* gen_expected, void* st_end, hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
-    k_set_leaves<<<(n + 255) / 256, 256, 0, s>>>(d, idx, val, n, gen, gen_expected);
-    for (int l = 1; l < n_levels; ++l) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, l, idx, n);
+    k_update_l01<<<(n + 3) / 4, 256, 0, s>>>(d, idx, val, n, gen, gen_expected);
+    rebuild_upper(d, st_end, s);          // levels >= 2 (+ optional fused step_end)
     return (int)hipGetLastError();
 }
 
@@ -169,7 +268,8 @@ DRL_API int drl_sumtree_ingest(float* base, int n_levels, const long long* off, 
     if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0 || n > cap) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
     k_ingest<<<(n + 255) / 256, 256, 0, s>>>(d, start, n, prio, gen, idx_scratch);
-    for (int l = 1; l < n_levels; ++l) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, l, idx_scratch, n);
+    if (n_levels > 1) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, 1, idx_scratch, n);
+    rebuild_upper(d, nullptr, s);
     return (int)hipGetLastError();
 }
 

@@ -94,8 +94,9 @@ class ApexEngine:
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
         # (online forward -> TD -> dgrad chain) and every kernel alone is too small to fill 256 CUs, so they are
         # forked onto side streams (captured as parallel branches of the hipGraph)
-        self.overlap = overlap
-        self.side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if overlap else []
+        import os
+        self.overlap = overlap and os.environ.get("DRL_OVERLAP", "1") != "0"
+        self.side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if self.overlap else []
         self._graphs = None
         self.steps_done = 0
 
@@ -119,9 +120,7 @@ class ApexEngine:
 
     def _forward_backward(self) -> None:
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
-        H.step_begin(self.st, r.n_items)
-        r.sample(self.st)
-        self.G.flat.zero_()
+        r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
         with self._fork(0):                                        # target net on s' || online net on [s ; s']
             torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
         torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
@@ -156,9 +155,8 @@ class ApexEngine:
         cfg = self.cfg
         H.grad_sumsq(self.G.flat, self.partial)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
-                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st)
-        self.replay.update(self.new_prio)
-        H.step_end(self.st)
+                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True)
+        self.replay.update(self.new_prio, end_state=self.st)        # step_end fused into the tree rebuild
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:

@@ -125,9 +125,7 @@ class R2D2Engine:
 
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
-        H.step_begin(self.st, r.n_items)
-        r.sample(self.st)
-        self.G.flat.zero_()
+        r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
         self._net_forward(self.Pb, self.P, self.on, self.bsum_on)
         self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
         H.is_weights(r.prio, self.st, self.w)
@@ -175,9 +173,9 @@ class R2D2Engine:
         cfg = self.cfg
         H.grad_sumsq(self.G.flat, self.partial)
         H.adam_step(self.P.flat, self.G.flat, self.M1.flat, self.M2.flat, self.Pb.flat, self.partial, self.n_partial,
-                    1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, self.st)
-        self.replay.update(self.new_prio)
-        H.step_end(self.st)
+                    1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, self.st,
+                    zero_grad=True)
+        self.replay.update(self.new_prio, end_state=self.st)        # step_end fused into the tree rebuild
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:

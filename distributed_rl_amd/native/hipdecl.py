@@ -8,8 +8,8 @@ SIGS = {
     # sumtree.hip
     "drl_step_begin": [P, P, P],
     "drl_step_end": [P, P],
-    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P],
-    "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P],
+    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P, P],
+    "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P],
     "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P],
     "drl_gather_rows": [P, P, P, I, I, P],
     "drl_gather_f32": [P, P, P, I, I, P],
@@ -20,8 +20,8 @@ SIGS = {
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
     "drl_grad_sumsq": [P, L, P, POINTER(c_int), P],
-    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, P],
-    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P],
+    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P],
     "drl_cast_bf16": [P, P, L, P],
     # head.hip
     "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],

@@ -95,22 +95,29 @@ class TreeLayout:
 
 def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
                    prio_out: torch.Tensor, gen: Optional[torch.Tensor] = None, gen_out: Optional[torch.Tensor] = None,
-                   frame_off: Optional[torch.Tensor] = None, frame_bytes: int = 0) -> None:
+                   frame_off: Optional[torch.Tensor] = None, frame_bytes: int = 0,
+                   begin_n_items: Optional[torch.Tensor] = None) -> None:
+    """``begin_n_items`` (int64 device scalar) fuses step_begin into the sampling kernel: beta / n_items of the step
+    state are refreshed and the Philox counter of step t is rng_ctr + t + 1 (do not also call step_begin then)."""
     B = idx_out.numel()
     _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
     if frame_off is not None:
         _chk(frame_off, torch.int64, "frame_off")
         assert frame_off.numel() >= 2 * B
     _ck(native.hip().drl_sumtree_sample(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(st), seed, B, _p(idx_out),
-                                        _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), frame_bytes, _s()), "sumtree_sample")
+                                        _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), frame_bytes, _p(begin_n_items),
+                                        _s()), "sumtree_sample")
 
 
 def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
-                   gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None) -> None:
+                   gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
+                   end_state: Optional[torch.Tensor] = None) -> None:
+    """Two launches for any depth: leaves + level 1 (one wave per index), then every level >= 2 rebuilt from level 1.
+    ``end_state`` fuses step_end (step += 1) into the second launch."""
     _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
     assert idx.numel() == val.numel()
     _ck(native.hip().drl_sumtree_update(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(idx), _p(val), idx.numel(),
-                                        _p(gen), _p(gen_expected), _s()), "sumtree_update")
+                                        _p(gen), _p(gen_expected), _p(end_state), _s()), "sumtree_update")
 
 
 def sumtree_ingest(tree: torch.Tensor, lay: TreeLayout, start: int, prio: torch.Tensor, gen: Optional[torch.Tensor],
@@ -168,14 +175,17 @@ def grad_sumsq(g: torch.Tensor, partial: torch.Tensor) -> int:
     return n.value
 
 
-def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st) -> None:
+def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st,
+                 zero_grad: bool = False) -> None:
+    """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch)."""
     _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
-                                      max_norm, lr, alpha, eps, _p(st), _s()), "rmsprop_step")
+                                      max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0, _s()), "rmsprop_step")
 
 
-def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st) -> None:
+def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st,
+              zero_grad: bool = False) -> None:
     _ck(native.hip().drl_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
-                                   max_norm, lr, b1, b2, eps, _p(st), _s()), "adam_step")
+                                   max_norm, lr, b1, b2, eps, _p(st), 1 if zero_grad else 0, _s()), "adam_step")
 
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
@@ -218,7 +228,10 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
                               scale, flags, splits, _s()), "gemm")
 
 
-CONV_FWD_DIRECT = True   # barrier-free direct kernels (conv_direct.hip); False = LDS-tiled implicit GEMM (gemm.hip)
+# layers whose forward uses the barrier-free direct kernels (conv_direct.hip); the others run the LDS-tiled implicit
+# GEMM (gemm.hip). Measured on MI355X at 1024 frames: conv1 20.6 us direct vs 35.4 tiled; conv2 21.3 vs 17.0; conv3
+# 16.5 vs 13.4 -> only conv1 goes direct by default.
+CONV_FWD_DIRECT = (1,)
 
 
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
@@ -226,7 +239,7 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
              variant: int = 0) -> None:
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
     _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
-    if (CONV_FWD_DIRECT if direct is None else direct) and relu:
+    if ((layer in CONV_FWD_DIRECT) if direct is None else direct) and relu:
         _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
             "conv_fwd_direct")
         return

@@ -113,14 +113,16 @@ class DevicePER:
             done += k
 
     # ---- sample / update (graph-capturable) -----------------------------------------------------
-    def sample(self, st: torch.Tensor) -> None:
-        """Draw ``batch_size`` slots ∝ priority into ``self.idx / prio / gen_s / frame_off``."""
+    def sample(self, st: torch.Tensor, begin: bool = False) -> None:
+        """Draw ``batch_size`` slots ∝ priority into ``self.idx / prio / gen_s / frame_off``. ``begin`` fuses
+        step_begin (beta / n_items refresh, fresh Philox counter) into the sampling kernel."""
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
-                         self.frame_bytes)
+                         self.frame_bytes, begin_n_items=self.n_items if begin else None)
 
-    def update(self, new_prio: torch.Tensor) -> None:
-        """Write back priorities of the last sample; slots overwritten since are skipped (generation check)."""
-        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s)
+    def update(self, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None) -> None:
+        """Write back priorities of the last sample; slots overwritten since are skipped (generation check).
+        ``end_state`` fuses step_end into the tree rebuild launch."""
+        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
 
     # host-API parity with PrioritizedMemory (tests / tools; not on the hot path)
     def update_priorities(self, indices, priorities) -> None:

@@ -107,12 +107,13 @@ class DeviceSequenceReplay:
             done_n += k
 
     # ---- graph-capturable ------------------------------------------------------------------------------
-    def sample(self, st: torch.Tensor) -> None:
-        H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s)
+    def sample(self, st: torch.Tensor, begin: bool = False) -> None:
+        H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s,
+                         begin_n_items=self.n_items if begin else None)
         H.seq_offsets(self.idx, self.T, self.frame_bytes, self.frame_off)
 
-    def update(self, new_prio: torch.Tensor) -> None:
-        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s)
+    def update(self, new_prio: torch.Tensor, end_state=None) -> None:
+        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
 
     def remove_to_fit(self) -> int:
         return 0

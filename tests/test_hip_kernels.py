@@ -92,6 +92,48 @@ def test_sumtree_ingest_total_sample_update(hip, cap):
     assert gen[0].item() == 2 and gen[cap - 1].item() == 1 + (1 if cap - 1 < n else 0)
 
 
+@pytest.mark.parametrize("cap", [50, 4000, 300_000, 2_000_000])
+def test_sumtree_fused_update_and_step(hip, cap):
+    """2-launch update (leaves + level 1, then all upper levels from level 1) with clustered duplicates, and the
+    fused step_begin / step_end variants."""
+    H = hip
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    scratch = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(cap + 1)
+    prio = torch.rand(cap, generator=g) + 0.01
+    H.sumtree_ingest(tree, lay, 0, prio.to(DEV), None, scratch)
+    st = H.new_step_state(DEV, 0.4, 100)
+    n_items = torch.tensor([cap], dtype=torch.int64, device=DEV)
+    B = 512
+    # clustered indices: many hits inside the same level-1 node, exact duplicates with different values
+    base = torch.randint(0, cap, (B,), generator=g)
+    base[:64] = (base[0] // 64 * 64 + torch.randint(0, 64, (64,), generator=g)).clamp(max=cap - 1)
+    base[100:110] = base[100]
+    ui = base.int().to(DEV)
+    uv = (torch.rand(B, generator=g) + 0.5)
+    ref = prio.clone()
+    for j in range(B):
+        ref[base[j]] = uv[j]                       # batch order, last entry wins
+    H.sumtree_update(tree, lay, ui, uv.to(DEV), end_state=st)
+    t = tree.cpu()
+    assert torch.equal(t[:cap], ref)
+    for lvl in range(1, lay.n_levels):
+        child = t[lay.offsets[lvl - 1]:lay.offsets[lvl - 1] + lay.sizes[lvl - 1]].view(-1, 64)
+        par = t[lay.offsets[lvl]:lay.offsets[lvl] + child.shape[0]]
+        torch.testing.assert_close(par, child.sum(1), rtol=2e-6, atol=0)
+    assert H.read_step_state(st)["step"] == 1     # step_end rode along
+    idx, p = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, device=DEV)
+    H.sumtree_sample(tree, lay, st, 7, idx, p, begin_n_items=n_items)
+    s1 = H.read_step_state(st)
+    assert s1["n_items"] == cap and s1["beta"] == pytest.approx(0.4 + 0.6 / 100)
+    assert s1["total_prio"] == pytest.approx(float(ref.double().sum()), rel=1e-5)
+    first = idx.clone()
+    H.sumtree_update(tree, lay, idx, p, end_state=st)          # same values: tree unchanged, step -> 2
+    H.sumtree_sample(tree, lay, st, 7, idx, p, begin_n_items=n_items)
+    assert not torch.equal(first, idx)            # fresh Philox counter per step without step_begin
+
+
 def test_gather_rows(hip):
     src = torch.randint(0, 256, (50, 28224), dtype=torch.uint8, device=DEV)
     off = (torch.tensor([4, 0, 49, 4, 17], dtype=torch.int64, device=DEV) * 28224)
