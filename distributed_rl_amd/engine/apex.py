@@ -27,6 +27,7 @@ from ..models import DuelingDQN
 from ..models.packing import ParamPack, apex_layout
 from ..ops import hip as H
 from ..replay.device_per import DevicePER
+from .streams import ForkJoin
 
 
 class TorsoBuffers:
@@ -92,11 +93,9 @@ class ApexEngine:
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
-        # (online forward -> TD -> dgrad chain) and every kernel alone is too small to fill 256 CUs, so they are
-        # forked onto side streams (captured as parallel branches of the hipGraph)
-        import os
-        self.overlap = overlap and os.environ.get("DRL_OVERLAP", "1") != "0"
-        self.side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if self.overlap else []
+        # (online forward -> TD -> dgrad chain); see engine/streams.py
+        self.fj = ForkJoin(dev, 2, overlap)
+        self.overlap = self.fj.enabled
         self._graphs = None
         self.steps_done = 0
 
@@ -106,17 +105,10 @@ class ApexEngine:
         self.Tb.flat.copy_(self.Pb.flat)
 
     def _fork(self, i: int):
-        """Context manager: run the body on side stream i after everything issued so far on the main stream."""
-        import contextlib
-        if not self.overlap:
-            return contextlib.nullcontext()
-        side = self.side[i]
-        side.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(side)
+        return self.fj.fork(i)
 
     def _join(self) -> None:
-        for side in self.side:
-            torch.cuda.current_stream().wait_stream(side)
+        self.fj.join()
 
     def _forward_backward(self) -> None:
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg

@@ -29,6 +29,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
+from .streams import ForkJoin
 from ..replay.device_seq import DeviceSequenceReplay
 
 
@@ -50,7 +51,7 @@ class SeqNetBuffers:
 class R2D2Engine:
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0):
+                 done_offset: int = 0, overlap: bool = True):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = dev = torch.device(device)
         self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
@@ -96,6 +97,7 @@ class R2D2Engine:
         self.wgrad_splits = wgrad_splits
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
+        self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
         self._graphs = None
         self.steps_done = 0
 
@@ -126,9 +128,12 @@ class R2D2Engine:
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
         r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
+        fj = self.fj
+        with fj.fork(0):                                            # target net || online net (240 small LSTM launches)
+            self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
         self._net_forward(self.Pb, self.P, self.on, self.bsum_on)
-        self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
         H.is_weights(r.prio, self.st, self.w)
+        fj.join()
         H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,
                   burn, cfg.nstep, self.done_offset, cfg.gamma_n, cfg.eta, cfg.rescale_eps, self.dq, self.new_prio)
         # ---- backward over rows [burn*B, T*B) ----
@@ -137,8 +142,9 @@ class R2D2Engine:
         h2, hs_out = on.h2[r0:], on.hs[burn + 1:].view(NB, Hd)
         H.head_bwd(self.dq.view(T * B, A)[r0:], h2, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh2, G.view("adv2.w"), None,
                    G.view("val2.w"), G.view("val2.b"))
-        H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
-        H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
+        with fj.fork(0):                                            # fc1 dW, db || the BPTT chain
+            H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+            H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
         H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
         # BPTT
         self.dh_rec.zero_()
@@ -151,23 +157,29 @@ class R2D2Engine:
                 H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=16, big=False)
         dG = self.dG.view(NB, 4 * Hd)
         a3 = on.act3[r0:]
-        H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
-        H.gemm(H.TN, dG, a3, G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
-        H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
-        G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
+        with fj.fork(1):                                            # LSTM weight gradients || input-gradient chain
+            H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+            H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
+            G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
+        with fj.fork(2):
+            H.gemm(H.TN, dG, a3, G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
         H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), self.d3.view(NB, 3136), NB, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
         sp = self.wgrad_splits
         a2, a1 = on.act2[r0:], on.act1[r0:]
-        H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), NB, splits=sp)
-        H.colsum(self.d3, G.view("conv3.b"), NB * 49, 64)
+        with fj.fork(0):
+            H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), NB, splits=sp)
+            H.colsum(self.d3, G.view("conv3.b"), NB * 49, 64)
         H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, NB)
         H.col2im(3, self.dcol3, a2, self.d2, NB)
-        H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), NB, splits=sp)
-        H.colsum(self.d2, G.view("conv2.b"), NB * 81, 64)
+        with fj.fork(1):
+            H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), NB, splits=sp)
+            H.colsum(self.d2, G.view("conv2.b"), NB * 81, 64)
         H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, NB)
         H.col2im(2, self.dcol2, a1, self.d1, NB)
+        with fj.fork(2):
+            H.colsum(self.d1, G.view("conv1.b"), NB * 400, 32)
         H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), NB, frame_off=r.frame_off[r0:], splits=2 * sp)
-        H.colsum(self.d1, G.view("conv1.b"), NB * 400, 32)
+        fj.join()
 
     def _optimize(self) -> None:
         cfg = self.cfg
