@@ -46,6 +46,8 @@ class SeqNetBuffers:
         self.gates = torch.zeros(T, B, 4 * Hd, **bf) if save_gates else None
         self.h2 = torch.zeros(N, 1024, **bf)
         self.q = torch.zeros(N, n_action, device=device)
+        self.sync = torch.zeros(4, dtype=torch.int32, device=device)   # persistent-recurrence arrival counters
+        self.err = torch.zeros(4, dtype=torch.int32, device=device)    # ... and its timeout flag
 
 
 class R2D2Engine:
@@ -98,6 +100,8 @@ class R2D2Engine:
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
+        import os
+        self.persistent_lstm = H.lstm_seq_supported(B, Hd) and os.environ.get("DRL_PERSISTENT_LSTM", "1") != "0"
         self._graphs = None
         self.steps_done = 0
 
@@ -118,9 +122,13 @@ class R2D2Engine:
         H.gather_state(r.h0, r.idx, None, buf.hs[0])
         H.gather_state(r.c0, r.idx, buf.cs[0], None)
         w_hh = wb.view("lstm.w_hh")
-        for t in range(T):
-            H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
-                        buf.gates[t] if buf.gates is not None else None)
+        if self.persistent_lstm:
+            # one launch for all T steps (csrc/hip/lstm_seq.hip) instead of T launches of the EPI_LSTM GEMM
+            H.lstm_seq_fwd([(buf.xg, w_hh, buf.hs, buf.cs, buf.gates)], T, B, Hd, buf.sync, buf.err)
+        else:
+            for t in range(T):
+                H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
+                            buf.gates[t] if buf.gates is not None else None)
         H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
                flags=H.EPI_RELU, big=True)
         H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
@@ -240,7 +248,11 @@ class R2D2Engine:
             self.sync_target()
 
     def stats(self) -> dict:
-        return H.read_step_state(self.st)
+        st = H.read_step_state(self.st)
+        if self.persistent_lstm and (int(self.on.err[0].item()) or int(self.tg.err[0].item())):
+            raise RuntimeError("persistent LSTM kernel: an inter-workgroup wait timed out (results invalid); "
+                               "set DRL_PERSISTENT_LSTM=0 to use per-step launches")
+        return st
 
     def state_dict(self):
         return self.P.state_dict()

@@ -282,6 +282,28 @@ def lstm_step(h_prev, w_hh, xg_t, c_prev, h_out, c_out, gates_out=None) -> None:
         "lstm_step")
 
 
+def lstm_seq_fwd(nets, T: int, M: int, Hd: int, sync: torch.Tensor, err: torch.Tensor) -> None:
+    """Persistent recurrence (csrc/hip/lstm_seq.hip): ONE launch runs all T steps of 1 or 2 networks.
+    ``nets`` = list of (xg [T,M,4H] f32, w_hh [4H,H] bf16 gate-interleaved, hs [T+1,M,H] bf16, cs [T+1,M,H] f32,
+    gates [T,M,4H] bf16 or None); hs[0] / cs[0] hold the initial state. ``sync`` (2 x int32) / ``err`` (1 x int32)
+    are device scratch; ``err`` turns non-zero if an inter-workgroup wait expired (check with lstm_seq_check)."""
+    assert 1 <= len(nets) <= 2
+    _chk(sync, torch.int32, "sync"); _chk(err, torch.int32, "err")
+    args = []
+    for xg, w_hh, hs, cs, gates in nets:
+        _chk(xg, torch.float32, "xg"); _chk(w_hh, torch.bfloat16, "w_hh"); _chk(hs, torch.bfloat16, "hs"); _chk(cs, torch.float32, "cs")
+        assert xg.numel() == T * M * 4 * Hd and hs.numel() == (T + 1) * M * Hd and cs.numel() == (T + 1) * M * Hd
+        assert w_hh.shape == (4 * Hd, Hd) and (gates is None or gates.numel() == T * M * 4 * Hd)
+        args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates)]
+    if len(nets) == 1:
+        args += [None] * 5
+    _ck(native.hip().drl_lstm_seq_fwd(*args, len(nets), T, M, Hd, _p(sync), _p(err), _s()), "lstm_seq_fwd")
+
+
+def lstm_seq_supported(M: int, Hd: int) -> bool:
+    return Hd == 512 and 0 < M <= 64 and M % 16 == 0
+
+
 def lstm_bwd_point(dh_head, dh_rec, dc, gates, c_t, c_prev, dgates) -> None:
     B, Hd = c_t.shape
     _chk(dh_rec, torch.float32, "dh_rec"); _chk(dc, torch.float32, "dc"); _chk(gates, torch.bfloat16, "gates")

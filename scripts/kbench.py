@@ -130,11 +130,26 @@ def main():
     xg_t, c0 = torch.randn(64, 2048, device=DEV), torch.zeros(64, 512, device=DEV)
     ho, co = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 512, device=DEV)
     cases["lstm_step"] = (lambda: H.lstm_step(hp, whh, xg_t, c0, ho, co, None), 2 * 64 * 2048 * 512, 0)
+    Ts = 120
+    xgs = torch.randn(Ts, 64, 2048, device=DEV) * 0.3
+    hss = torch.zeros(Ts + 1, 64, 512, dtype=torch.bfloat16, device=DEV)
+    css = torch.zeros(Ts + 1, 64, 512, device=DEV)
+    gts = torch.zeros(Ts, 64, 2048, dtype=torch.bfloat16, device=DEV)
+    hss2, css2 = hss.clone(), css.clone()
+    sync, err = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def steps120():
+        for t in range(Ts):
+            H.lstm_step(hss[t], whh, xgs[t], css[t], hss[t + 1], css[t + 1], gts[t])
+    cases["lstm_120_steps"] = (steps120, 2 * 64 * 2048 * 512 * Ts, 0)
+    cases["lstm_seq_1net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts)], Ts, 64, 512, sync, err), 2 * 64 * 2048 * 512 * Ts, 0)
+    cases["lstm_seq_2net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts), (xgs, whh, hss2, css2, None)], Ts, 64, 512, sync, err),
+                              2 * 2 * 64 * 2048 * 512 * Ts, 0)
     print("%-18s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
     for name, (fn, flops, byts) in cases.items():
         if args.only and args.only not in name:
             continue
-        us = timeit(fn, args.reps)
+        us = timeit(fn, 3 if name.startswith("lstm_1") or name.startswith("lstm_seq") else args.reps)
         print("%-18s %10.1f %10.1f %10.1f" % (name, us, flops / us / 1e6, byts / us / 1e3))
 
 

@@ -93,13 +93,13 @@ def test_apex_engine_graph_equals_eager_and_learns():
     a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
     assert torch.isfinite(a).all()
     assert (a - b).norm() / a.norm() < 1e-3          # same RNG stream, same data; atomics reorder only
-    # loss goes down on a fixed tiny replay
-    first = None
-    for i in range(150):
+    # loss goes down on a fixed tiny replay (window means: single PER batches are noisy)
+    losses = []
+    for i in range(240):
         e2.step()
-        if i == 0:
-            first = e2.stats()["loss"]
-    assert e2.stats()["loss"] < first
+        losses.append(e2.stats()["loss"])
+    assert all(l == l for l in losses)
+    assert sum(losses[-40:]) < sum(losses[:40]), (losses[:40], losses[-40:])
 
 
 def test_device_per_block_ingest_roundtrip():
@@ -200,11 +200,34 @@ def test_r2d2_engine_step_matches_oracle():
 def test_r2d2_engine_graph_runs_and_learns():
     _, cfg, rep, eng = _r2d2_setup(seed=3)
     eng.use_graph = True
+    cfg.lr = 1e-3                      # read at capture time; 10x the default so 40 sequences are fitted within the test
     losses = []
-    for i in range(200):
+    for i in range(300):
         eng.step()
         losses.append(eng.stats()["loss"])
     s = eng.stats()
-    assert eng._graphs[0] == "one" and s["step"] == 201
+    assert eng._graphs[0] == "one" and s["step"] == 301
     assert all(l == l for l in losses)
-    assert sum(losses[-20:]) < sum(losses[1:21]), (losses[1:21], losses[-20:])
+    assert sum(losses[-50:]) < 0.9 * sum(losses[1:51]), (losses[1:51], losses[-50:])
+
+
+def test_r2d2_engine_persistent_lstm_matches_step_launches():
+    """B = 16 takes the one-launch persistent recurrence; DRL_PERSISTENT_LSTM=0 the per-step EPI_LSTM GEMMs."""
+    import os
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["DRL_PERSISTENT_LSTM"] = flag
+        try:
+            _, cfg, rep, eng = _r2d2_setup(B=16, cap=48, seed=4)
+        finally:
+            os.environ.pop("DRL_PERSISTENT_LSTM", None)
+        assert eng.persistent_lstm == (flag == "1")
+        eng._forward_backward()
+        torch.cuda.synchronize()
+        st = eng.stats()
+        outs.append((eng.on.q.clone(), eng.tg.q.clone(), eng.G.flat.clone(), st["loss"]))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=2e-2, atol=2e-2)
+    assert outs[0][3] == pytest.approx(outs[1][3], rel=3e-2)
+    gn0, gn1 = outs[0][2].norm(), outs[1][2].norm()
+    assert float((outs[0][2] - outs[1][2]).norm() / gn1) < 5e-2 and float(gn0) > 0

@@ -473,3 +473,50 @@ def test_conv_dgrad(hip, layer, frames):
     H.col2im(layer, dcol, x.to(DEV), dx, frames)
     ref = xin.grad.permute(0, 2, 3, 1) * (xf > 0)
     torch.testing.assert_close(dx.float().cpu(), ref, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
+
+
+# ---- LSTM recurrence -----------------------------------------------------------------------------------
+def _lstm_case(T, M, Hd, seed):
+    from distributed_rl_amd.models.packing import _gate_interleave
+    g = torch.Generator().manual_seed(seed)
+    w_hh = bf(torch.randn(4 * Hd, Hd, generator=g) * 0.04)          # PyTorch row order [i; f; g; o]
+    xg = torch.randn(T, M, 4 * Hd, generator=g) * 0.5
+    h0 = bf(torch.randn(M, Hd, generator=g) * 0.3)
+    c0 = torch.randn(M, Hd, generator=g) * 0.3
+    hs_ref, cs_ref = oracle.lstm_unroll(xg, w_hh.float(), h0.float(), c0)
+    w_k = _gate_interleave(w_hh, Hd).to(DEV)
+    xg_k = _gate_interleave(xg.permute(2, 0, 1).contiguous(), Hd).permute(1, 2, 0).contiguous().to(DEV)
+    return w_k, xg_k, h0, c0, hs_ref, cs_ref
+
+
+@pytest.mark.parametrize("M", [16, 48, 64])
+def test_lstm_step_and_persistent_sequence(hip, M):
+    """T single-step launches (EPI_LSTM GEMM) and the persistent one-launch recurrence against the fp32 oracle."""
+    H = hip
+    T, Hd = 12, 512
+    w_k, xg_k, h0, c0, hs_ref, cs_ref = _lstm_case(T, M, Hd, 100 + M)
+    outs = []
+    for mode in ("step", "seq", "seq2"):
+        hs = torch.zeros(T + 1, M, Hd, dtype=torch.bfloat16, device=DEV)
+        cs = torch.zeros(T + 1, M, Hd, device=DEV)
+        gates = torch.zeros(T, M, 4 * Hd, dtype=torch.bfloat16, device=DEV)
+        hs[0], cs[0] = h0.to(DEV), c0.to(DEV)
+        if mode == "step":
+            for t in range(T):
+                H.lstm_step(hs[t], w_k, xg_k[t], cs[t], hs[t + 1], cs[t + 1], gates[t])
+        else:
+            sync, err = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+            nets = [(xg_k, w_k, hs, cs, gates)]
+            if mode == "seq2":                                      # second network in the same launch, no gates
+                hs2, cs2 = hs.clone(), cs.clone()
+                nets.append((xg_k, w_k, hs2, cs2, None))
+            H.lstm_seq_fwd(nets, T, M, Hd, sync, err)
+            assert int(err.item()) == 0
+            if mode == "seq2":
+                assert torch.equal(hs2, hs) and torch.equal(cs2, cs)
+        torch.testing.assert_close(hs[1:].float().cpu(), hs_ref, rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(cs[1:].cpu(), cs_ref, rtol=3e-2, atol=3e-2)
+        outs.append((hs.float().cpu(), cs.cpu(), gates.float().cpu()))
+    # both kernels see identical bf16 operands: they agree far tighter than either agrees with fp32
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=2e-2, atol=1e-2)
+    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=2e-2, atol=1e-2)
