@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 PAPER_APEX_TRANSITIONS_PER_S = 9700.0     # ~19 batches/s x 512 (recalled from Horgan et al. 2018)
 PAPER_R2D2_UPDATES_PER_S = 5.0
 PAPER_ACTOR_FPS = 50000.0
+PAPER_R2D2_ACTOR_FPS = 66000.0             # 256 actors x ~260 fps (recalled from Kapturowski et al. 2019)
 
 
 def timed(dist, fn, steps, warmup):
@@ -118,6 +119,13 @@ def main():
             extra["r2d2_sequence_steps_per_s"] = args.r2d2_steps / r_dt * rcfg.batch_size * rcfg.seq_len * dist.world_size
             extra["r2d2_vs_paper"] = extra["r2d2_updates_per_s"] / PAPER_R2D2_UPDATES_PER_S
             extra["r2d2_replay_sequences_per_gpu"] = scap
+            from distributed_rl_amd.engine.r2d2_actor import R2D2ActorEngine
+            del reng, srep
+            torch.cuda.empty_cache()
+            ract = R2D2ActorEngine(args.n_action, args.actor_envs, rcfg, dev)
+            ra_dt = timed(dist, ract.step_host, 50, 5)          # recurrent actor: frames in over PCIe, actions out
+            extra["r2d2_actor_env_frames_per_s"] = 4 * args.actor_envs * 50 / ra_dt * dist.world_size
+            extra["r2d2_actor_vs_paper"] = extra["r2d2_actor_env_frames_per_s"] / PAPER_R2D2_ACTOR_FPS
         except Exception as e:
             extra["r2d2_error"] = repr(e)[:200]
 

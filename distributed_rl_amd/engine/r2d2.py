@@ -50,6 +50,33 @@ class SeqNetBuffers:
         self.err = torch.zeros(4, dtype=torch.int32, device=device)    # ... and its timeout flag
 
 
+def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
+                    wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, persistent: bool) -> None:
+    """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0]:
+    time-batched torso (3 conv launches over all T*B frames) -> one input-projection GEMM for all steps -> the
+    recurrence (one persistent launch, or T launches of the EPI_LSTM GEMM) -> time-batched FC + dueling head.
+    Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
+    sequence-priority pass (dense frames, ``frame_off`` None)."""
+    N = T * B
+    H.conv_fwd(1, frames, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, N, frame_off)
+    H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
+    H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, N)
+    H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
+    H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), buf.xg.view(N, 4 * Hd), N, 4 * Hd, 3136, bias=bsum,
+           flags=H.EPI_OUT_F32, big=N >= 1024)
+    w_hh = wb.view("lstm.w_hh")
+    if persistent:
+        # one launch for all T steps (csrc/hip/lstm_seq.hip) instead of T launches of the EPI_LSTM GEMM
+        H.lstm_seq_fwd([(buf.xg, w_hh, buf.hs, buf.cs, buf.gates)], T, B, Hd, buf.sync, buf.err)
+    else:
+        for t in range(T):
+            H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
+                        buf.gates[t] if buf.gates is not None else None)
+    H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
+           flags=H.EPI_RELU, big=N >= 1024)
+    H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
+
+
 class R2D2Engine:
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
@@ -111,27 +138,10 @@ class R2D2Engine:
 
     # ---- forward of one net over the whole sampled batch ---------------------------------------------------
     def _net_forward(self, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor) -> None:
-        r, T, B, Hd = self.replay, self.T, self.B, self.Hd
-        N = T * B
-        H.conv_fwd(1, r.frames, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, N, r.frame_off)
-        H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
-        H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, N)
-        H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
-        H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), buf.xg.view(N, 4 * Hd), N, 4 * Hd, 3136, bias=bsum,
-               flags=H.EPI_OUT_F32, big=True)
+        r = self.replay
         H.gather_state(r.h0, r.idx, None, buf.hs[0])
         H.gather_state(r.c0, r.idx, buf.cs[0], None)
-        w_hh = wb.view("lstm.w_hh")
-        if self.persistent_lstm:
-            # one launch for all T steps (csrc/hip/lstm_seq.hip) instead of T launches of the EPI_LSTM GEMM
-            H.lstm_seq_fwd([(buf.xg, w_hh, buf.hs, buf.cs, buf.gates)], T, B, Hd, buf.sync, buf.err)
-        else:
-            for t in range(T):
-                H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
-                            buf.gates[t] if buf.gates is not None else None)
-        H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
-               flags=H.EPI_RELU, big=True)
-        H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
+        seq_net_forward(r.frames, r.frame_off, self.T, self.B, self.Hd, wb, wf, buf, bsum, self.persistent_lstm)
 
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn

@@ -13,7 +13,8 @@ R2D2 adds recurrent-state recording, overlapping sequence assembly and sequence 
 (r2d2/actor.py:39-87); pulling params also refreshes the actor-side target net (r2d2/actor.py:89-91).
 
 The inference function is pluggable: ``policy`` is either an ``nn.Module`` (CPU / oracle path) or an
-``engine.ActorEngine`` (gfx950 path: fused torso → head → ε-greedy with device-side RNG).
+``engine.ActorEngine`` / ``engine.R2D2ActorEngine`` (gfx950 path: fused torso → [LSTM step →] head → ε-greedy with
+device-side RNG; R2D2 sequence priorities through the learner's time-batched forward + fused TD kernel).
 """
 from __future__ import annotations
 
@@ -155,6 +156,14 @@ class Actor:
     def _publish_r2d2(self) -> None:
         seqs, self.local = self.local[:self.cfg.actor_batch], self.local[self.cfg.actor_batch:]
         dev = self.device
+        if self.engine is not None:       # gfx950 path: time-batched forward of both nets + fused TD kernel
+            prio = self.engine.sequence_priorities(
+                np.stack([s.frames for s in seqs], 1), np.stack([s.action for s in seqs], 1),
+                np.stack([s.reward for s in seqs], 1), np.stack([s.done for s in seqs], 1),
+                np.array([s.length for s in seqs], dtype=np.int32), np.stack([s.h0 for s in seqs]),
+                np.stack([s.c0 for s in seqs]))
+            self._send_sequences(seqs, prio)
+            return
         frames = torch.from_numpy(np.stack([s.frames for s in seqs], 1)).to(dev)          # (T,K,…)
         action = torch.from_numpy(np.stack([s.action for s in seqs], 1)).to(dev)
         reward = torch.from_numpy(np.stack([s.reward for s in seqs], 1)).to(dev)
@@ -166,6 +175,9 @@ class Actor:
                                   self.cfg.gamma_n, self.cfg.rescale_eps, require_grad=False,
                                   done_offset=self.cfg.nstep if self.cfg.reference_nstep_order else 0)
         prio = td.prio.float().cpu().numpy()
+        self._send_sequences(seqs, prio)
+
+    def _send_sequences(self, seqs, prio) -> None:
         T, H = seqs[0].frames.shape[0], seqs[0].h0.shape[0]
         per = max(1, (getattr(self.exp, "slot_bytes", 1 << 62) - codec.HEADER_BYTES - 4096) //
                   codec.r2d2_block_bytes(1, T, H, tuple(seqs[0].frames.shape[1:])))
@@ -196,8 +208,11 @@ class Actor:
                 break
             obs = self.env.current_obs()
             if self.is_r2d2:
-                h_before = self.net.hx.detach().cpu().numpy()
-                c_before = self.net.cx.detach().cpu().numpy()
+                if self.engine is not None:
+                    h_before, c_before = self.engine.get_state()
+                else:
+                    h_before = self.net.hx.detach().cpu().numpy()
+                    c_before = self.net.cx.detach().cpu().numpy()
             action = self.act(obs)
             next_obs, reward, done, info = self.env.step(action)
             scores += reward
@@ -205,7 +220,10 @@ class Actor:
             if self.is_r2d2:
                 self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
                 if done.any():
-                    self.net.reset(torch.from_numpy(done))
+                    if self.engine is not None:
+                        self.engine.reset(done)
+                    else:
+                        self.net.reset(torch.from_numpy(done))
             else:
                 out = self.asm.step(obs, action, r, next_obs, done)
                 if out is not None:

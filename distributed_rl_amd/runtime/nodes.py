@@ -57,7 +57,7 @@ def actor_main(argv=None) -> int:
     parser.add_argument('--actor-batch', type=int, default=None)
     parser.add_argument('--param-period', type=int, default=None)
     parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
-                        help='hip = batched gfx950 inference engine (Ape-X; needs a GPU).')
+                        help='hip = batched gfx950 inference engine (Ape-X and R2D2; needs a GPU).')
     _common(parser)
     args = parser.parse_args(argv)
     from .actor import Actor
@@ -79,10 +79,18 @@ def actor_main(argv=None) -> int:
         actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, heartbeat=hb, seed=args.seed,
                       engine=engine)
     else:
-        net = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)
-        tgt = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to(device)
-        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, target_net=tgt,
-                      heartbeat=hb, seed=args.seed)
+        engine = None
+        use_hip = args.engine == 'hip' or (args.engine == 'auto' and device.type == 'cuda')
+        net = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to('cpu' if use_hip else device)
+        tgt = DuelingLSTMDQN(env.n_action, args.num_envs, cfg.burn_in, cfg.nstep).to('cpu' if use_hip else device)
+        if use_hip:
+            from ..engine.r2d2_actor import R2D2ActorEngine
+            from ..utils import epsilon_ladder
+            eps = epsilon_ladder(args.num_envs, (args.no - 1) * args.num_envs + 1, args.num_total_actors * args.num_envs)
+            engine = R2D2ActorEngine(env.n_action, args.num_envs, cfg, device, eps=eps, seed=args.seed or args.no,
+                                     init_model=net, done_offset=cfg.nstep if cfg.reference_nstep_order else 0)
+        actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, 'cpu' if use_hip else device,
+                      target_net=tgt, heartbeat=hb, seed=args.seed, engine=engine)
     actor.pull_params()
     try:
         actor.run(max_steps=args.max_steps)

@@ -109,3 +109,83 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     m = DuelingLSTMDQN(4, 8, 4, 2)
     m.load_state_dict(sd)
     assert tuple(sd["lstm.weight_hh"].shape) == (2048, 512)
+
+
+def test_r2d2_actor_engine_matches_module():
+    """Recurrent actor engine: step-by-step Q / state vs the PyTorch module (incl. reset), sequence priorities vs
+    model.sequence_td, parameter refresh."""
+    from distributed_rl_amd.config import R2D2Config
+    from distributed_rl_amd.engine.r2d2_actor import R2D2ActorEngine
+    torch.manual_seed(0)
+    E, A = 16, 5
+    cfg = R2D2Config(burn_in=4, seq_len=8, nstep=2)
+    m = DuelingLSTMDQN(A, E, cfg.burn_in, cfg.nstep)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    m.eval()
+    m.hx, m.cx = torch.zeros(E, 512), torch.zeros(E, 512)
+    eng = R2D2ActorEngine(A, E, cfg, "cuda", eps=np.zeros(E, np.float32), init_model=m)
+    rng = np.random.default_rng(0)
+    for step in range(6):
+        obs = rng.integers(0, 256, (E, 84, 84, 4), dtype=np.uint8)
+        h_before, c_before = eng.get_state()
+        np.testing.assert_allclose(h_before, m.hx.numpy(), rtol=5e-2, atol=3e-2)
+        np.testing.assert_allclose(c_before, m.cx.numpy(), rtol=5e-2, atol=3e-2)
+        a = eng.act(obs)
+        with torch.no_grad():
+            q = m(torch.from_numpy(obs))
+        torch.testing.assert_close(eng.q_values().cpu(), q, rtol=5e-2, atol=5e-2)
+        top2 = q.topk(2, 1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 0.1
+        assert (torch.from_numpy(a)[clear] == q.argmax(1)[clear]).all()
+        if step == 2:
+            done = np.zeros(E, bool)
+            done[[1, 7]] = True
+            eng.reset(done)
+            m.reset(torch.from_numpy(done))
+    # sequence priorities
+    T, K = cfg.total_len, 5
+    frames = rng.integers(0, 256, (T, K, 84, 84, 4), dtype=np.uint8)
+    action = rng.integers(0, A, (T, K)).astype(np.int32)
+    reward = rng.standard_normal((T, K)).astype(np.float32)
+    done = np.zeros((T, K), np.float32)
+    lengths = np.array([T, T, T - 2, T, T - 3], dtype=np.int32)
+    done[T - 3, 2] = done[T - 4, 4] = 1.0
+    h0 = (rng.standard_normal((K, 512)) * 0.2).astype(np.float32)
+    c0 = (rng.standard_normal((K, 512)) * 0.2).astype(np.float32)
+    pr = eng.sequence_priorities(frames, action, reward, done, lengths, h0, c0)
+    tgt = DuelingLSTMDQN(A, K, cfg.burn_in, cfg.nstep)
+    tgt.load_state_dict(m.state_dict())
+    mk = DuelingLSTMDQN(A, K, cfg.burn_in, cfg.nstep)
+    mk.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        td = mk.sequence_td(tgt, torch.from_numpy(frames), torch.from_numpy(action).long(), torch.from_numpy(reward),
+                            torch.from_numpy(done), torch.from_numpy(lengths), torch.from_numpy(h0).to(torch.bfloat16).float(),
+                            torch.from_numpy(c0), None, cfg.eta, cfg.gamma_n, cfg.rescale_eps, require_grad=False)
+    np.testing.assert_allclose(pr, td.prio.numpy(), rtol=0.1, atol=0.03)
+    # parameter refresh also refreshes the actor-side target
+    from distributed_rl_amd.models import ParamPack
+    m2 = DuelingLSTMDQN(A, E, cfg.burn_in, cfg.nstep)
+    eng.load_flat(ParamPack.from_module(m2).flat.numpy())
+    assert torch.equal(eng.Tb.flat, eng.Pb.flat)
+
+
+def test_r2d2_runtime_actor_with_engine_publishes_sequences(run_id):
+    from distributed_rl_amd.engine.r2d2_actor import R2D2ActorEngine
+    from distributed_rl_amd.transport import codec
+    cfg = make_config("r2d2", burn_in=4, seq_len=8, overlap=4, nstep=2, actor_batch=4, actor_param_period=50)
+    exp, par = connect("inproc", run_id, create=True)
+    E = 4
+    env = envs.make_vec("SyntheticCatch-v0", E, seed=0)
+    net = DuelingLSTMDQN(env.n_action, E, cfg.burn_in, cfg.nstep)
+    tgt = DuelingLSTMDQN(env.n_action, E, cfg.burn_in, cfg.nstep)
+    eng = R2D2ActorEngine(env.n_action, E, cfg, "cuda", init_model=net)
+    actor = Actor(1, env, net, cfg, exp, par, None, 1, "cpu", target_net=tgt, seed=0, engine=eng)
+    actor.run(max_steps=60)
+    assert actor.published_blocks > 0
+    blocks = exp.drain()
+    assert len(blocks) > 0
+    b = blocks[0]
+    assert b["frames"].shape[1:] == (cfg.total_len, 84, 84, 4) and b["h0"].shape[1] == 512
+    assert np.isfinite(b["prio"]).all() and (b["prio"] >= 0).all()
