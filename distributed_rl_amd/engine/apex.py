@@ -92,6 +92,7 @@ class ApexEngine:
         self.wgrad_splits = wgrad_splits
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
+        self.n_scale = 1.0                               # N_global / (world * N_local): see refresh_shard_scalars
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
         # (online forward -> TD -> dgrad chain); see engine/streams.py
         self.fj = ForkJoin(dev, 2, overlap)
@@ -103,6 +104,20 @@ class ApexEngine:
     def sync_target(self) -> None:
         self.T.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
+
+    def refresh_shard_scalars(self) -> float:
+        """Sharded PER: rank r draws its batch from its own shard, so item i is drawn with probability
+        p_i / (world * Σp_local) and its single-tree-equivalent IS weight is (N_global * p_i / (world * Σp_local))^-β.
+        The TD kernel computes (n_scale * N_local * p_i / Σp_local)^-β, hence n_scale = N_global / (world * N_local)
+        (= 1 for equally filled shards). One tiny all-reduce, called at capture time (the value is baked into the graph)
+        and by the learner whenever the fill level changed materially."""
+        if self.dist is None or not self.dist.enabled:
+            self.n_scale = 1.0
+            return 1.0
+        n_local = int(self.replay.n_items.item())
+        _, n_global = self.dist.shard_scalars(0.0, n_local)
+        self.n_scale = float(n_global) / float(max(1, self.world * n_local))
+        return self.n_scale
 
     def _fork(self, i: int):
         return self.fj.fork(i)
@@ -118,7 +133,7 @@ class ApexEngine:
         torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
         self._join()
         H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                  cfg.prio_eps, self.dq, self.new_prio, n_scale=1.0)
+                  cfg.prio_eps, self.dq, self.new_prio, n_scale=self.n_scale)
         G, Pb, on = self.G, self.Pb, self.on
         h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
@@ -163,6 +178,7 @@ class ApexEngine:
     def capture(self) -> None:
         """Warm up eagerly, then capture. world==1: one graph. world>1: try one graph including the RCCL
         all-reduce; if the collective cannot be captured fall back to graph / eager all-reduce / graph."""
+        self.refresh_shard_scalars()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
