@@ -93,6 +93,9 @@ class ApexEngine:
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.n_scale = 1.0                               # N_global / (world * N_local): see refresh_shard_scalars
+        import os as _os
+        self.overlap_comm = _os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
+        self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
         # (online forward -> TD -> dgrad chain); see engine/streams.py
         self.fj = ForkJoin(dev, 2, overlap)
@@ -126,6 +129,13 @@ class ApexEngine:
         self.fj.join()
 
     def _forward_backward(self) -> None:
+        self._fb_head()
+        self._fb_torso()
+
+    def _fb_head(self) -> None:
+        """Sampling, both forwards, TD, and the backward of head + FC1. After it the gradient of everything from
+        ``fc1.w`` to the end of the flat buffer (97.6 % of the parameters) is final - multi-GPU runs start its
+        all-reduce here, under the conv backward that follows."""
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
         r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
         with self._fork(0):                                        # target net on s' || online net on [s ; s']
@@ -143,6 +153,13 @@ class ApexEngine:
             H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh, G.view("fc1.b"), B, 1024)
         H.gemm(H.NN, self.dh, Pb.view("fc1.w"), self.d3.view(B, 3136), B, 3136, 1024, mask=a3, flags=H.EPI_MASK, big=False)
+
+    def _fb_torso(self) -> None:
+        """Backward of conv3 -> conv1 (weight gradients on side streams); joins every side stream at the end."""
+        B, r = self.B, self.replay
+        G, Pb, on = self.G, self.Pb, self.on
+        a2, a1 = on.act2[:B], on.act1[:B]
+        sp = self.wgrad_splits
         with self._fork(1):                                        # conv3 dW, db || conv3 dX
             H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
             H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
@@ -169,11 +186,35 @@ class ApexEngine:
         if self.dist is not None and self.dist.enabled:
             self.dist.all_reduce_flat(self.G.flat)
 
+    def _dist_on(self) -> bool:
+        return self.dist is not None and self.dist.enabled
+
     # ---- step ---------------------------------------------------------------------------------------
     def _eager_step(self) -> None:
+        if self._dist_on() and self.overlap_comm:
+            self._overlapped_step(self._fb_head_joined, self._fb_torso, self._optimize)
+            return
         self._forward_backward()
         self._all_reduce()
         self._optimize()
+
+    def _fb_head_joined(self) -> None:
+        self._fb_head()
+        self._join()
+
+    def _overlapped_step(self, head, torso, optimize) -> None:
+        """Data-parallel step with the gradient all-reduce hidden under the backward pass: the FC1/head slice of the
+        flat gradient (12.9 of 13.2 MB) is reduced on RCCL's stream WHILE the conv backward runs on the compute
+        stream; only the 0.3 MB conv slice is reduced after it. xGMI is point-to-point, the payload is latency-bound:
+        two collectives per step, never per-tensor buckets."""
+        cut = self._grad_cut
+        head()
+        w_big = self.dist.all_reduce_async(self.G.flat[cut:])
+        torso()
+        w_small = self.dist.all_reduce_async(self.G.flat[:cut])
+        w_big.wait()
+        w_small.wait()
+        optimize()
 
     def capture(self) -> None:
         """Warm up eagerly, then capture. world==1: one graph. world>1: try one graph including the RCCL
@@ -194,8 +235,19 @@ class ApexEngine:
             with torch.cuda.graph(g):
                 self._eager_step()
             self._graphs = ("one", g)
+        elif self.overlap_comm:
+            # default for multi-GPU: three graphs, the two RCCL all-reduces issued between them on RCCL's own stream
+            # (the big one overlaps the conv-backward graph)
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._fb_head_joined()
+            with torch.cuda.graph(g2):
+                self._fb_torso()
+            with torch.cuda.graph(g3):
+                self._optimize()
+            self._graphs = ("overlap", g1, g2, g3)
         else:
-            # default for multi-GPU: two graphs with the flat all-reduce issued eagerly between them
+            # two graphs with ONE flat all-reduce issued eagerly between them
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._forward_backward()
@@ -210,6 +262,9 @@ class ApexEngine:
                 self.capture()
             if self._graphs[0] == "one":
                 self._graphs[1].replay()
+            elif self._graphs[0] == "overlap":
+                _, g1, g2, g3 = self._graphs
+                self._overlapped_step(g1.replay, g2.replay, g3.replay)
             else:
                 self._graphs[1].replay()
                 self._all_reduce()

@@ -20,6 +20,11 @@ import torch
 import torch.distributed as td
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class Dist:
     def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: int = 600):
         import datetime
@@ -48,6 +53,13 @@ class Dist:
         """SUM over ranks, in place, one collective for the whole gradient."""
         if self.enabled:
             td.all_reduce(flat, op=td.ReduceOp.SUM)
+
+    def all_reduce_async(self, flat: torch.Tensor):
+        """SUM over ranks, in place, asynchronous: the collective runs on the backend's own stream after the work
+        already queued on the current stream; ``.wait()`` on the returned handle orders the current stream after it."""
+        if not self.enabled:
+            return _Done()
+        return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self, module: torch.nn.Module) -> None:
         """PyTorch-learner path: flatten → one all-reduce → average → scatter back."""
