@@ -38,7 +38,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #define NTHREADS 256
 
-enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16 };
+enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16, EPI_REMAP = 32 };
 
 struct Epilogue {
     void* C;
@@ -56,6 +56,9 @@ struct Epilogue {
     float* c_out;           // [Mo][No/4]
     bf16_t* h_out;          // [Mo][No/4]
     bf16_t* gates_out;      // [Mo][No] post-activation i,f,g,o (for BPTT), may be null
+    // EPI_REMAP (implicit dgrad): GEMM row m = (b, yy, xx) of parity class (py, px) -> NHWC pixel row
+    // (b*rm_h + rm_s*yy + py)*rm_w + rm_s*xx + px, used for the C store and the mask load
+    int rm_hc, rm_wc, rm_s, rm_h, rm_w, rm_py, rm_px;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -73,6 +76,9 @@ struct DenseOp {
     __device__ __forceinline__ bool row_ok(int r) const { return r < rows; }
     __device__ __forceinline__ off_t row_base(int r) const { return (off_t)r * (off_t)ld; }
     __device__ __forceinline__ int col_off(int c) const { return c; }
+    __device__ __forceinline__ off_t addr(off_t rb, int c) const { return rb + (off_t)c; }
+    __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
+    static constexpr bool HAS_CLASS = false;
     typedef uint4 raw_t;     // 8 bf16
     __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
     __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
@@ -106,6 +112,9 @@ struct ConvOp {
         int kh = kc / KWC;
         return kh * (W * C) + (kc - kh * KWC);
     }
+    __device__ __forceinline__ off_t addr(off_t rb, int kc) const { return rb + (off_t)col_off(kc); }
+    __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
+    static constexpr bool HAS_CLASS = false;
     // raw 8 elements as they sit in memory (8 bytes for uint8 frames, 16 for bf16); widened to bf16 only when the
     // tile is written to LDS, so the global loads stay in flight across the MFMA phase instead of being consumed
     // by the conversion right after issue.
@@ -136,6 +145,73 @@ struct ConvOp {
             return v;
         }
     }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Implicit input-gradient (dgrad) operands: dX[b,y,x,ci] = sum_{ky,kx,co} dY[b,(y-ky)/S,(x-kx)/S,co] * W[co,ky,kx,ci]
+// as ONE GEMM per stride-parity class (py, px) = (y % S, x % S): only the taps ky = py + S*ty, kx = px + S*tx touch a
+// pixel of that class, so M = frames*(H/S)*(W/S) pixels, K = (KS/S)^2 * CO ordered (ty, tx, co), N = CI. No dCol matrix
+// is materialised and no col2im pass runs (the dCol GEMM + col2im pair moved 58 / 84 MB per step for conv3 / conv2 at
+// B=512; this form moves 8.5 / 18 MB). blockIdx.z selects the class (HAS_CLASS), the epilogue maps the class-local row
+// back to the NHWC pixel and applies the ReLU mask of the layer input.
+// ---------------------------------------------------------------------------------------------------
+template <int H_, int W_, int KS_, int S_, int CO_>
+struct DgradOp {          // A operand (normal orientation): rows = pixels of one parity class, k = (ty, tx, co)
+    static constexpr int H = H_, W = W_, KS = KS_, S = S_, CO = CO_;
+    static constexpr int OH = (H_ - KS_) / S_ + 1, OW = (W_ - KS_) / S_ + 1, TS = KS_ / S_, HC = H_ / S_, WC = W_ / S_;
+    static constexpr int K = TS * TS * CO_;
+    static_assert(KS_ % S_ == 0 && H_ % S_ == 0 && W_ % S_ == 0, "parity classes must tile the input");
+    static constexpr bool HAS_CLASS = true;
+    const bf16_t* p;      // dY [frames][OH][OW][CO]
+    int rows;             // frames*HC*WC (per class)
+    int py, px;           // set from blockIdx.z in the kernel
+    __device__ __forceinline__ void set_class(int z) { py = z / S; px = z % S; }
+    // row handle: bits 0..39 element offset of dY[b][yy][xx][0] (may point past the valid window), 40..47 yy, 48..55 xx
+    typedef unsigned long long off_t;
+    __device__ __forceinline__ bool row_ok(int m) const { return m < rows; }
+    __device__ __forceinline__ off_t row_base(int m) const {
+        const int mm = m < rows ? m : 0;
+        const int b = mm / (HC * WC), rem = mm - b * (HC * WC), yy = rem / WC, xx = rem - yy * WC;
+        const off_t o = (off_t)((long long)(b * OH + yy) * OW + xx) * CO;
+        return o | ((off_t)yy << 40) | ((off_t)xx << 48);
+    }
+    __device__ __forceinline__ int col_off(int c) const { return c; }
+    __device__ __forceinline__ bool pair_ok(off_t rb, int k) const {
+        const int tap = k / CO, ty = tap / TS, tx = tap - ty * TS;
+        const int oy = (int)((rb >> 40) & 0xff) - ty, ox = (int)((rb >> 48) & 0xff) - tx;
+        return oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+    }
+    __device__ __forceinline__ off_t addr(off_t rb, int k) const {
+        const int tap = k / CO, ty = tap / TS, tx = tap - ty * TS;
+        return (rb & 0xffffffffffull) - (off_t)((ty * OW + tx) * CO) + (off_t)(k - tap * CO);
+    }
+    typedef uint4 raw_t;
+    __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
+    __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
+};
+
+template <int KS_, int S_, int CI_, int CO_>
+struct WdgradOp {         // B operand (transposed orientation, memory rows = k): W[co][ky][kx][ci], k = (ty, tx, co)
+    static constexpr int TS = KS_ / S_, K = TS * TS * CO_;
+    static constexpr bool HAS_CLASS = true;
+    const bf16_t* p;
+    int py, px;
+    __device__ __forceinline__ void set_class(int z) { py = z / S_; px = z % S_; }
+    typedef unsigned off_t;
+    __device__ __forceinline__ bool row_ok(int k) const { return k < K; }
+    __device__ __forceinline__ off_t row_base(int k) const {
+        const int kk = k < K ? k : 0;
+        const int tap = kk / CO_, co = kk - tap * CO_, ty = tap / TS, tx = tap - ty * TS;
+        return (off_t)(co * (KS_ * KS_ * CI_) + ((py + S_ * ty) * KS_ + (px + S_ * tx)) * CI_);
+    }
+    __device__ __forceinline__ int col_off(int c) const { return c; }
+    __device__ __forceinline__ off_t addr(off_t rb, int c) const { return rb + (off_t)c; }
+    __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
+    typedef uint4 raw_t;
+    __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
+    __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -198,8 +274,10 @@ struct Stage {
             typename Op::off_t rb;
             bool ok = active && kidx < Kc;
             if constexpr (TR) { rb = op.row_base(kidx); ok = ok && op.row_ok(kidx); }
-            else { rb = rc.base[i]; ok = ok && ((rc.ok >> i) & 1u); }
-            const typename Op::off_t off = ok ? rb + (typename Op::off_t)op.col_off(TR ? out0 + c * 8 : kidx) : 0;
+            else { rb = rc.base[i]; ok = ok && ((rc.ok >> i) & 1u) && op.pair_ok(rb, kidx); }
+            typename Op::off_t off;
+            if constexpr (TR) off = ok ? rb + (typename Op::off_t)op.col_off(out0 + c * 8) : 0;
+            else off = ok ? op.addr(rb, kidx) : 0;
             reg[i] = op.load_raw(off);
             valid |= (ok ? 1u : 0u) << i;
         }
@@ -245,6 +323,14 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
 // ---------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
 __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
+    constexpr bool CLASSES = AOp::HAS_CLASS;     // blockIdx.z = stride-parity class of an implicit dgrad (no split-K)
+    static_assert(AOp::HAS_CLASS == BOp::HAS_CLASS, "both operands must agree on classes");
+    if constexpr (CLASSES) {
+        aop.set_class(blockIdx.z);
+        bop.set_class(blockIdx.z);
+        ep.rm_py = aop.py;
+        ep.rm_px = aop.px;
+    }
     static_assert(WM * WN == 4, "4 waves");
     static_assert(D >= 2 && D % 2 == 0, "ring depth");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;    // MFMA tiles per wave
@@ -258,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int nkt = (Kc + BKT - 1) / BKT;
-    const int kt0 = blockIdx.z * kt_per, kt1 = min(kt0 + kt_per, nkt);
+    const int kt0 = CLASSES ? 0 : blockIdx.z * kt_per, kt1 = min(kt0 + kt_per, nkt);
     if (kt0 >= kt1) return;
 
     f32x4 acc[TM][TN];
@@ -341,6 +427,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
         if (m >= Mo) continue;
+        long long mrow = m;                  // row of C / mask in memory
+        if (flags & EPI_REMAP) {
+            const int b = m / (ep.rm_hc * ep.rm_wc), rem = m - b * (ep.rm_hc * ep.rm_wc), yy = rem / ep.rm_wc, xx = rem - yy * ep.rm_wc;
+            mrow = ((long long)b * ep.rm_h + ep.rm_s * yy + ep.rm_py) * ep.rm_w + ep.rm_s * xx + ep.rm_px;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
@@ -366,17 +457,17 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
             }
             if (flags & EPI_MASK) {
-                uint2 mk = *reinterpret_cast<const uint2*>(ep.mask + (long long)m * ep.ldmask + n);
+                uint2 mk = *reinterpret_cast<const uint2*>(ep.mask + mrow * ep.ldmask + n);
                 // bf16 > 0  <=>  sign bit clear and not zero
                 uint32_t e[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) if (e[t] == 0 || (e[t] & 0x8000u)) v[t] = 0.f;
             }
             if (flags & EPI_OUT_F32) {
-                float* c = reinterpret_cast<float*>(ep.C) + (long long)m * ep.ldc + n;
+                float* c = reinterpret_cast<float*>(ep.C) + mrow * ep.ldc + n;
                 *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(ep.C) + (long long)m * ep.ldc + n;
+                bf16_t* c = reinterpret_cast<bf16_t*>(ep.C) + mrow * ep.ldc + n;
                 *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             }
         }
@@ -384,14 +475,16 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
 }
 
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
-static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s) {
+static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s,
+                  int classes = 0) {
     if (No % BN != 0 || Mo <= 0 || Kc <= 0) return -2;
     const int nkt = (Kc + BKT - 1) / BKT;
     if (splits < 1) splits = 1;
     if (splits > nkt) splits = nkt;
-    const int kt_per = (nkt + splits - 1) / splits;
+    int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;
-    if (splits > 1 && !(ep.flags & EPI_ATOMIC)) return -3;
+    if (classes > 0) { kt_per = nkt; splits = classes; }     // grid.z = parity classes, each runs the whole K range
+    if (splits > 1 && !classes && !(ep.flags & EPI_ATOMIC)) return -3;
     dim3 grid(No / BN, (Mo + BM - 1) / BM, splits);
     size_t lds = 2 * (size_t)(BM + BN) * BKT * 2;
     if ((ep.flags & EPI_ATOMIC) && lds < (size_t)BM * (BN + 4) * 4) lds = (size_t)BM * (BN + 4) * 4;
@@ -416,6 +509,7 @@ static Epilogue make_epi(void* C, long long ldc, const float* bias, const void* 
     Epilogue e;
     e.C = C; e.ldc = ldc; e.bias = bias; e.mask = (const bf16_t*)mask; e.ldmask = ldmask; e.scale = scale; e.flags = flags;
     e.xg = nullptr; e.ldxg = 0; e.c_prev = nullptr; e.c_out = nullptr; e.h_out = nullptr; e.gates_out = nullptr;
+    e.rm_hc = e.rm_wc = e.rm_s = e.rm_h = e.rm_w = 1; e.rm_py = e.rm_px = 0;
     return e;
 }
 
@@ -527,6 +621,29 @@ DRL_API int drl_conv_dcol(int layer, const void* dy, int frames, const void* w, 
         DenseOp A{(const bf16_t*)dy, 64, M}, B{(const bf16_t*)w, Conv3Op::K, 64};
         return launch<128, 64, 64, 2, 2, false, true, 2>(A, B, M, Conv3Op::K, 64, 1, make_epi(dcol, Conv3Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
     }
+    return -1;
+}
+
+// ---- conv input gradient, implicit form: dX = relu'(act_in) * dgrad(dY, W), one launch, no dCol / col2im ----
+// layer 2: dY [frames][9][9][64], W [64][4][4][32] -> dX [frames][20][20][32];  layer 3: dY [frames][7][7][64],
+// W [64][3][3][64] -> dX [frames][9][9][64]. act_in = forward input of the layer (ReLU mask), same shape as dX.
+template <int H, int W, int KS, int S, int CI, int CO, int BM, int BN, int WM, int WN>
+static int launch_dgrad(const void* dy, const void* w, const void* act_in, void* dx, int frames, hipStream_t s) {
+    typedef DgradOp<H, W, KS, S, CO> AOp;
+    typedef WdgradOp<KS, S, CI, CO> BOp;
+    const int M = frames * AOp::HC * AOp::WC;
+    if ((long long)frames * AOp::OH * AOp::OW * CO >= (1LL << 40)) return -8;
+    AOp A{(const bf16_t*)dy, M, 0, 0};
+    BOp B{(const bf16_t*)w, 0, 0};
+    Epilogue ep = make_epi(dx, CI, nullptr, act_in, CI, 1.0f, (act_in ? EPI_MASK : 0) | EPI_REMAP);
+    ep.rm_hc = AOp::HC; ep.rm_wc = AOp::WC; ep.rm_s = S; ep.rm_h = H; ep.rm_w = W;
+    return launch<BM, BN, 64, WM, WN, false, true, 2>(A, B, M, CI, AOp::K, 1, ep, s, S * S);
+}
+
+DRL_API int drl_conv_dgrad(int layer, const void* dy, int frames, const void* w, const void* act_in, void* dx, hipStream_t s) {
+    if (frames <= 0) return -1;
+    if (layer == 2) return launch_dgrad<20, 20, 4, 2, 32, 64, 128, 32, 4, 1>(dy, w, act_in, dx, frames, s);
+    if (layer == 3) return launch_dgrad<9, 9, 3, 1, 64, 64, 128, 64, 2, 2>(dy, w, act_in, dx, frames, s);
     return -1;
 }
 

@@ -174,9 +174,13 @@ DRL_API int drl_head_fwd(const void* h, int M, int A, const void* w_adv, const f
 }
 
 DRL_API int drl_head_bwd(const float* dq, const void* h, int M, int A, const void* w_adv, const void* w_val, void* dh,
-                         float* gw_adv, float* gb_adv, float* gw_val, float* gb_val, hipStream_t s) {
+                         float* gw_adv, float* gb_adv, float* gw_val, float* gb_val, int parts, hipStream_t s) {
+    // parts: bit 0 = input gradient dh (on the critical path), bit 1 = weight / bias gradients (independent of it:
+    // the engines issue it on a side stream)
     if (M <= 0 || A <= 0 || A > MAX_A) return -1;
-    k_head_bwd_dh<<<(M + 3) / 4, 256, 0, s>>>(dq, (const bf16_t*)h, M, A, (const bf16_t*)w_adv, (const bf16_t*)w_val, (bf16_t*)dh);
-    k_head_bwd_dw<<<dim3(4, (M + DW_ROWS - 1) / DW_ROWS), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
+    if (parts & 1)
+        k_head_bwd_dh<<<(M + 3) / 4, 256, 0, s>>>(dq, (const bf16_t*)h, M, A, (const bf16_t*)w_adv, (const bf16_t*)w_val, (bf16_t*)dh);
+    if (parts & 2)
+        k_head_bwd_dw<<<dim3(4, (M + DW_ROWS - 1) / DW_ROWS), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
     return (int)hipGetLastError();
 }

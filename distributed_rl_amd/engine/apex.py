@@ -147,8 +147,11 @@ class ApexEngine:
         G, Pb, on = self.G, self.Pb, self.on
         h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
-        H.head_bwd(self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
-                   G.view("val2.w"), G.view("val2.b"))
+        hb = (self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
+              G.view("val2.w"), G.view("val2.b"))
+        with self._fork(1):                                        # head dW, db: off the critical path
+            H.head_bwd(*hb, parts=2)
+        H.head_bwd(*hb, parts=1)                                   # dh
         with self._fork(0):                                        # fc1 dW, db || fc1 dX
             H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh, G.view("fc1.b"), B, 1024)
@@ -163,17 +166,24 @@ class ApexEngine:
         with self._fork(1):                                        # conv3 dW, db || conv3 dX
             H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
             H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
-        H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, B)
-        H.col2im(3, self.dcol3, a2, self.d2, B)
+        self._dgrad(3, self.d3, Pb.view("conv3.w"), self.dcol3, a2, self.d2, B)
         with self._fork(0):                                        # conv2 dW, db || conv2 dX
             H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), B, splits=sp)
             H.colsum(self.d2, G.view("conv2.b"), B * 81, 64)
-        H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, B)
-        H.col2im(2, self.dcol2, a1, self.d1, B)
+        self._dgrad(2, self.d2, Pb.view("conv2.w"), self.dcol2, a1, self.d1, B)
         with self._fork(1):
             H.colsum(self.d1, G.view("conv1.b"), B * 400, 32)
         H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), B, frame_off=r.frame_off, splits=4 * sp)
         self._join()
+
+    @staticmethod
+    def _dgrad(layer, dy, w, dcol, act_in, dx, n) -> None:
+        """d(pre-activation) of the previous layer: implicit one-launch dgrad, or dCol GEMM + col2im gather."""
+        if H.CONV_DGRAD_IMPLICIT:
+            H.conv_dgrad(layer, dy, w, act_in, dx, n)
+        else:
+            H.conv_dcol(layer, dy, w, dcol, n)
+            H.col2im(layer, dcol, act_in, dx, n)
 
     def _optimize(self) -> None:
         cfg = self.cfg

@@ -158,8 +158,11 @@ class R2D2Engine:
         G, Pb, on = self.G, self.Pb, self.on
         r0 = burn * B
         h2, hs_out = on.h2[r0:], on.hs[burn + 1:].view(NB, Hd)
-        H.head_bwd(self.dq.view(T * B, A)[r0:], h2, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh2, G.view("adv2.w"), None,
-                   G.view("val2.w"), G.view("val2.b"))
+        hb = (self.dq.view(T * B, A)[r0:], h2, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh2, G.view("adv2.w"), None,
+              G.view("val2.w"), G.view("val2.b"))
+        with fj.fork(1):                                            # head dW, db: off the critical path
+            H.head_bwd(*hb, parts=2)
+        H.head_bwd(*hb, parts=1)
         with fj.fork(0):                                            # fc1 dW, db || the BPTT chain
             H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
@@ -187,17 +190,24 @@ class R2D2Engine:
         with fj.fork(0):
             H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), NB, splits=sp)
             H.colsum(self.d3, G.view("conv3.b"), NB * 49, 64)
-        H.conv_dcol(3, self.d3, Pb.view("conv3.w"), self.dcol3, NB)
-        H.col2im(3, self.dcol3, a2, self.d2, NB)
+        self._dgrad(3, self.d3, Pb.view("conv3.w"), self.dcol3, a2, self.d2, NB)
         with fj.fork(1):
             H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), NB, splits=sp)
             H.colsum(self.d2, G.view("conv2.b"), NB * 81, 64)
-        H.conv_dcol(2, self.d2, Pb.view("conv2.w"), self.dcol2, NB)
-        H.col2im(2, self.dcol2, a1, self.d1, NB)
+        self._dgrad(2, self.d2, Pb.view("conv2.w"), self.dcol2, a1, self.d1, NB)
         with fj.fork(2):
             H.colsum(self.d1, G.view("conv1.b"), NB * 400, 32)
         H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), NB, frame_off=r.frame_off[r0:], splits=2 * sp)
         fj.join()
+
+    @staticmethod
+    def _dgrad(layer, dy, w, dcol, act_in, dx, n) -> None:
+        """d(pre-activation) of the previous layer: implicit one-launch dgrad, or dCol GEMM + col2im gather."""
+        if H.CONV_DGRAD_IMPLICIT:
+            H.conv_dgrad(layer, dy, w, act_in, dx, n)
+        else:
+            H.conv_dcol(layer, dy, w, dcol, n)
+            H.col2im(layer, dcol, act_in, dx, n)
 
     def _optimize(self) -> None:
         cfg = self.cfg

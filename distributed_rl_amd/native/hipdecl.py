@@ -25,7 +25,7 @@ SIGS = {
     "drl_cast_bf16": [P, P, L, P],
     # head.hip
     "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],
-    "drl_head_bwd": [P, P, I, I, P, P, P, P, P, P, P, P],
+    "drl_head_bwd": [P, P, I, I, P, P, P, P, P, P, P, I, P],
     # gemm.hip
     "drl_gemm": [I, I, P, L, P, L, I, I, I, P, L, P, P, L, F, I, I, P],
     "drl_conv_fwd": [I, P, P, I, P, P, P, I, P],
@@ -33,6 +33,7 @@ SIGS = {
     # conv_direct.hip
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
+    "drl_conv_dgrad": [I, P, I, P, P, P, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip
     "drl_lstm_seq_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P],

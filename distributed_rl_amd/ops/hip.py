@@ -203,11 +203,12 @@ def head_fwd(h, w_adv, b_adv, w_val, b_val, q_out, action_out=None, eps=None, ep
                                   eps_mod, seed, _p(ctr), _s()), "head_fwd")
 
 
-def head_bwd(dq, h, w_adv, w_val, dh, gw_adv, gb_adv, gw_val, gb_val) -> None:
+def head_bwd(dq, h, w_adv, w_val, dh, gw_adv, gb_adv, gw_val, gb_val, parts: int = 3) -> None:
+    """parts: 1 = input gradient dh only, 2 = weight / bias gradients only, 3 = both."""
     M, A = dq.shape
     _chk(dq, torch.float32, "dq"); _chk(h, torch.bfloat16, "h"); _chk(dh, torch.bfloat16, "dh")
     _ck(native.hip().drl_head_bwd(_p(dq), _p(h), M, A, _p(w_adv), _p(w_val), _p(dh), _p(gw_adv), _p(gb_adv), _p(gw_val),
-                                  _p(gb_val), _s()), "head_bwd")
+                                  _p(gb_val), parts, _s()), "head_bwd")
 
 
 # ---- GEMM / conv ---------------------------------------------------------------------------------------
@@ -256,6 +257,17 @@ def conv_wgrad(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, 
 def conv_dcol(layer: int, dy: torch.Tensor, w: torch.Tensor, dcol: torch.Tensor, frames: int) -> None:
     _chk(dy, torch.bfloat16, "dy"); _chk(w, torch.bfloat16, "w"); _chk(dcol, torch.bfloat16, "dcol")
     _ck(native.hip().drl_conv_dcol(layer, _p(dy), frames, _p(w), _p(dcol), _s()), "conv_dcol")
+
+
+def conv_dgrad(layer: int, dy: torch.Tensor, w: torch.Tensor, act_in: Optional[torch.Tensor], dx: torch.Tensor,
+               frames: int) -> None:
+    """Implicit input gradient of conv2 / conv3 in ONE launch (no dCol matrix, no col2im pass):
+    dx = relu'(act_in) * conv_transpose(dy, w); act_in None = no mask."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
+    _ck(native.hip().drl_conv_dgrad(layer, _p(dy), frames, _p(w), _p(act_in), _p(dx), _s()), "conv_dgrad")
+
+
+CONV_DGRAD_IMPLICIT = True     # False = dCol GEMM + col2im gather (the two-pass form)
 
 
 def col2im(layer: int, dcol: torch.Tensor, act_in: torch.Tensor, dx: torch.Tensor, frames: int) -> None:

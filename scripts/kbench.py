@@ -106,12 +106,14 @@ def main():
         cases["conv3_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(3, a2[:B], d3v, g3, B, splits=sp), 2 * B * 49 * 64 * 576, B * 10368)
         cases["conv2_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(2, a1[:B], d2v, g2, B, splits=sp), 2 * B * 81 * 64 * 512, B * 25600)
         cases["conv1_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(1, x[:B], d1v, g1, B, splits=2 * sp), 2 * B * 400 * 32 * 256, B * 28224)
+    dx2 = torch.zeros(B, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
+    dx1 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
     dc3 = torch.zeros(B * 49, 576, dtype=torch.bfloat16, device=DEV)
     dc2 = torch.zeros(B * 81, 512, dtype=torch.bfloat16, device=DEV)
     cases["conv3_dcol"] = (lambda: H.conv_dcol(3, d3v, w3, dc3, B), 2 * B * 49 * 64 * 576, 2 * B * 49 * 576)
     cases["conv2_dcol"] = (lambda: H.conv_dcol(2, d2v, w2, dc2, B), 2 * B * 81 * 64 * 512, 2 * B * 81 * 512)
-    dx2 = torch.zeros(B, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
-    dx1 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    cases["conv3_dgrad_impl"] = (lambda: H.conv_dgrad(3, d3v, w3, a2[:B], dx2, B), 2 * B * 81 * 64 * 576, 2 * B * (49 + 81) * 64)
+    cases["conv2_dgrad_impl"] = (lambda: H.conv_dgrad(2, d2v, w2, a1[:B], dx1, B), 2 * B * 400 * 32 * 256, 2 * B * (81 * 64 + 400 * 32))
     cases["col2im3"] = (lambda: H.col2im(3, dc3, a2[:B], dx2, B), 0, 2 * B * 49 * 576)
     cases["col2im2"] = (lambda: H.col2im(2, dc2, a1[:B], dx1, B), 0, 2 * B * 81 * 512)
     db = torch.zeros(64, device=DEV)

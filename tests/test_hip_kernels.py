@@ -458,7 +458,7 @@ def test_colsum_shapes(hip, M, N):
 
 
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("frames", [2, 33])
+@pytest.mark.parametrize("frames", [2, 33, 300])
 def test_conv_dgrad(hip, layer, frames):
     H = hip
     x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 13 + frames)
@@ -473,6 +473,14 @@ def test_conv_dgrad(hip, layer, frames):
     H.col2im(layer, dcol, x.to(DEV), dx, frames)
     ref = xin.grad.permute(0, 2, 3, 1) * (xf > 0)
     torch.testing.assert_close(dx.float().cpu(), ref, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
+    # implicit one-launch form (parity-class GEMM, fused mask): same result without the dCol round trip
+    dx2 = torch.full_like(dx, 7.0)
+    H.conv_dgrad(layer, dy.to(DEV), w.to(DEV), x.to(DEV), dx2, frames)
+    torch.testing.assert_close(dx2.float().cpu(), ref, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
+    dx3 = torch.full_like(dx, 7.0)
+    H.conv_dgrad(layer, dy.to(DEV), w.to(DEV), None, dx3, frames)
+    ref_nomask = xin.grad.permute(0, 2, 3, 1)
+    torch.testing.assert_close(dx3.float().cpu(), ref_nomask, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
 
 
 # ---- LSTM recurrence -----------------------------------------------------------------------------------
