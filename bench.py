@@ -82,6 +82,13 @@ def main():
     H.cast_bf16(eng.P.flat, eng.Pb.flat)
     eng.sync_target()
 
+    try:
+        eng.step()                       # first step = eager warm-up + graph capture
+    except Exception as e:               # never lose the measurement to a capture problem: fall back to eager launches
+        if dist.rank == 0:
+            print("graph capture failed (%r); running eagerly" % (e,), file=sys.stderr)
+        eng.use_graph, eng._graphs = False, None
+        torch.cuda.synchronize()
     dt = timed(dist, eng.step, args.steps, args.warmup)
     ms = 1e3 * dt / args.steps
     updates_s = args.steps / dt

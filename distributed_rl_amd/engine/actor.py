@@ -19,6 +19,7 @@ import torch
 from ..models import DuelingDQN
 from ..models.packing import ParamPack, apex_layout
 from ..ops import hip as H
+from .streams import capture_graph
 from ..utils import epsilon_ladder
 from .apex import TorsoBuffers, torso_forward
 
@@ -80,7 +81,7 @@ class ActorEngine:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with capture_graph(self._graph):
                 self._launch()
         self._graph.replay()
         return self.action

@@ -27,7 +27,7 @@ from ..models import DuelingDQN
 from ..models.packing import ParamPack, apex_layout
 from ..ops import hip as H
 from ..replay.device_per import DevicePER
-from .streams import ForkJoin
+from .streams import ForkJoin, capture_graph
 
 
 class TorsoBuffers:
@@ -242,26 +242,26 @@ class ApexEngine:
         if not collective or os.environ.get("DRL_GRAPH_COLLECTIVES") == "1":
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):
                 self._eager_step()
             self._graphs = ("one", g)
         elif self.overlap_comm:
             # default for multi-GPU: three graphs, the two RCCL all-reduces issued between them on RCCL's own stream
             # (the big one overlaps the conv-backward graph)
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with capture_graph(g1):
                 self._fb_head_joined()
-            with torch.cuda.graph(g2):
+            with capture_graph(g2):
                 self._fb_torso()
-            with torch.cuda.graph(g3):
+            with capture_graph(g3):
                 self._optimize()
             self._graphs = ("overlap", g1, g2, g3)
         else:
             # two graphs with ONE flat all-reduce issued eagerly between them
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with capture_graph(g1):
                 self._forward_backward()
-            with torch.cuda.graph(g2):
+            with capture_graph(g2):
                 self._optimize()
             self._graphs = ("split", g1, g2)
         self.steps_done += 2

@@ -29,7 +29,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
-from .streams import ForkJoin
+from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
 
 
@@ -238,15 +238,15 @@ class R2D2Engine:
         if not collective or os.environ.get("DRL_GRAPH_COLLECTIVES") == "1":
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):
                 self._eager_step()
             self._graphs = ("one", g)
         else:
             # default for multi-GPU: two graphs with the flat all-reduce issued eagerly between them
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with capture_graph(g1):
                 self._forward_backward()
-            with torch.cuda.graph(g2):
+            with capture_graph(g2):
                 self._optimize()
             self._graphs = ("split", g1, g2)
         self.steps_done += 1

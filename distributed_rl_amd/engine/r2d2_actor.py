@@ -25,6 +25,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
+from .streams import capture_graph
 from ..utils import epsilon_ladder
 from .r2d2 import SeqNetBuffers, seq_net_forward
 
@@ -132,7 +133,7 @@ class R2D2ActorEngine:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with capture_graph(self._graph):
                 self._launch()
             self.h.copy_(h0)
             self.c.copy_(c0)

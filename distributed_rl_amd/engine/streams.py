@@ -32,3 +32,10 @@ class ForkJoin:
         cur = torch.cuda.current_stream()
         for side in self.side:
             cur.wait_stream(side)
+
+
+def capture_graph(graph: "torch.cuda.CUDAGraph"):
+    """``torch.cuda.graph`` with thread-local capture errors: other threads of the process (the RCCL watchdog polling
+    its events, the ingest thread's H2D copies, metrics) may touch the HIP runtime while a step is being captured;
+    only calls of the CAPTURING thread may invalidate the capture."""
+    return torch.cuda.graph(graph, capture_error_mode="thread_local")
