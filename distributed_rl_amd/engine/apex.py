@@ -239,8 +239,9 @@ class ApexEngine:
         torch.cuda.synchronize()
         import os
         collective = self.dist is not None and self.dist.enabled
-        if not collective or os.environ.get("DRL_GRAPH_COLLECTIVES") == "1":
-            # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
+        if not collective or self.dist.graph_collectives:
+            # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduces (overlapped schedule included) are
+            # captured into it as well: no host work at all between sampling and the priority write-back
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):
                 self._eager_step()

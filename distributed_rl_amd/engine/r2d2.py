@@ -235,7 +235,7 @@ class R2D2Engine:
         torch.cuda.synchronize()
         import os
         collective = self.dist is not None and self.dist.enabled
-        if not collective or os.environ.get("DRL_GRAPH_COLLECTIVES") == "1":
+        if not collective or self.dist.graph_collectives:
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):

@@ -75,6 +75,53 @@ class Dist:
             g.copy_(flat[o:o + n].view_as(g))
             o += n
 
+    # ---- collectives inside hipGraphs -------------------------------------------------------------------
+    @property
+    def graph_collectives(self) -> bool:
+        """May the engines capture RCCL collectives INTO their step graph (no host work between graph pieces: 0.32 vs
+        0.38 ms per Ape-X step at one rank)? ``DRL_GRAPH_COLLECTIVES`` = 0 / 1 decides when set; otherwise a trial
+        decides once: a small all-reduce is captured, replayed twice and checked on every rank, and the ranks agree
+        on the verdict (MIN) so that all of them build the same kind of step."""
+        env = os.environ.get("DRL_GRAPH_COLLECTIVES")
+        if env in ("0", "1"):
+            return env == "1"
+        if getattr(self, "_graph_ok", None) is None:
+            self._graph_ok = self._trial_graph_collective()
+        return self._graph_ok
+
+    def _trial_graph_collective(self) -> bool:
+        if not self.enabled or self.device.type != "cuda" or self.backend != "nccl":
+            return False
+        ok = 1.0
+        try:
+            x = torch.ones(4096, device=self.device)
+            td.all_reduce(x)                                   # communicator warm-up outside capture
+            torch.cuda.synchronize(self.device)
+            buf = torch.ones(4096, device=self.device)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    w = td.all_reduce(buf, op=td.ReduceOp.SUM, async_op=True)
+                    w.wait()
+                    buf.mul_(1.0 / self.world_size)            # back to ones: replays are idempotent
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize(self.device)
+            if not bool(torch.allclose(buf, torch.ones_like(buf), rtol=1e-5)):
+                ok = 0.0
+        except Exception:
+            ok = 0.0
+        try:                                                   # agree across ranks (eager collective)
+            v = torch.tensor([ok], device=self.device)
+            td.all_reduce(v, op=td.ReduceOp.MIN)
+            ok = float(v.item())
+        except Exception:
+            ok = 0.0
+        return ok > 0.5
+
     def broadcast_flat(self, flat: torch.Tensor, src: int = 0) -> None:
         if self.enabled:
             td.broadcast(flat, src=src)

@@ -111,6 +111,7 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
     import socket
     from distributed_rl_amd.parallel.dist import Dist
     monkeypatch.setenv("DRL_FORCE_DIST", "1")
+    monkeypatch.setenv("DRL_GRAPH_COLLECTIVES", "0")            # 3-graph schedule first
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         monkeypatch.setenv("MASTER_PORT", str(sk.getsockname()[1]))
@@ -141,6 +142,17 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
             e3.step()
         torch.cuda.synchronize()
         assert (a - e3.P.flat.cpu()).norm() / a.norm() < 3e-3
+        # collectives captured INTO one graph; without the env override a cross-rank trial decides
+        monkeypatch.delenv("DRL_GRAPH_COLLECTIVES")
+        assert dist.graph_collectives is True                   # RCCL captures fine on this stack
+        _, _, rep4, e4 = _setup(seed=2)
+        e4.use_graph = True
+        e4.dist = dist
+        for _ in range(6):
+            e4.step()
+        torch.cuda.synchronize()
+        assert e4._graphs[0] == "one" and e4.stats()["step"] == 8
+        assert (a - e4.P.flat.cpu()).norm() / a.norm() < 3e-3
     finally:
         dist.close()
 
