@@ -29,6 +29,7 @@ class HipLearner:
         self.is_r2d2 = algorithm == "r2d2"
         self.params.reset()
         self.exp.reset()
+        replay_size = self._fit_capacity(replay_size, cfg)
         if self.is_r2d2:
             from ..replay.device_seq import DeviceSequenceReplay
             from .r2d2 import R2D2Engine
@@ -44,6 +45,24 @@ class HipLearner:
         self.step = 0
         self._last_pub = 0.0
         self.ingested = 0
+
+    def _fit_capacity(self, want: int, cfg) -> int:
+        """The replay lives in HBM: clamp the requested item count to what fits next to the engine's activations (75 %
+        of the free memory). The reference's default ``-s 100000`` means 100 000 SEQUENCES for R2D2 = 315 GiB of uint8
+        frames; an MI355X holds ~65 000 of them (and ~3.8 M Ape-X transitions)."""
+        import warnings
+        if self.device.type != "cuda":
+            return want
+        free, _ = torch.cuda.mem_get_info(self.device)
+        if self.is_r2d2:
+            per_item = cfg.total_len * (28224 + 16) + 2 * 4 * cfg.hidden + 64
+        else:
+            per_item = 2 * 28224 + 64
+        fit = int(free * 0.75 // per_item)
+        if want > fit:
+            warnings.warn("replay size %d does not fit in HBM (%.0f GiB free): using %d" % (want, free / 2 ** 30, fit))
+            return max(fit, cfg.batch_size)
+        return want
 
     # ---- pieces -------------------------------------------------------------------------------------
     def ingest(self, max_blocks: Optional[int] = None) -> int:
