@@ -518,6 +518,7 @@ static Epilogue make_epi(void* C, long long ldc, const float* bias, const void* 
 // mode 1 (NN): C[M][N] = A[M][K] . B[K][N]            a = A, b = B [K][N]
 // mode 2 (TN): C[M][N] = A[K][M]^T . B[K][N]          a = A [K][M], b = B [K][N]   (contraction over memory rows)
 // variant: 0 = 64x64x64 ring 4 | 1 = 128x128x64 ring 2 | 2 = 64x64x128 ring 2 | 3 = 64x64x256 ring 2 | 4 = 128x64x128 ring 2
+//          5 = 64x32x64 ring 4 | 6 = 32x64x64 ring 4 (twice the workgroups of variant 0: two per CU for the 1024x1024 FC)
 template <bool A_TR, bool B_TR>
 static int dense_dispatch(int variant, const DenseOp& A, const DenseOp& B, int M, int N, int K, int splits, const Epilogue& ep,
                           hipStream_t s) {
@@ -527,6 +528,8 @@ static int dense_dispatch(int variant, const DenseOp& A, const DenseOp& B, int M
         case 2: return launch<64, 64, 128, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
         case 3: return launch<64, 64, 256, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
         case 4: return launch<128, 64, 128, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
+        case 5: return launch<64, 32, 64, 4, 1, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
+        case 6: return launch<32, 64, 64, 1, 4, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
     }
     return -7;
 }
@@ -539,7 +542,7 @@ DRL_API int drl_gemm(int mode, int variant, const void* a, long long lda, const 
     Epilogue ep = make_epi(C, ldc, bias, mask, ldmask, scale, flags);
     const bf16_t* pa = (const bf16_t*)a;
     const bf16_t* pb = (const bf16_t*)b;
-    const int bm = (variant == 1 || variant == 4) ? 128 : 64;
+    const int bm = (variant == 1 || variant == 4) ? 128 : (variant == 6 ? 32 : 64);
     if (mode == 0) {
         if (K % 8) return -5;
         DenseOp A{pa, lda, M}, B{pb, ldb, N};

@@ -50,13 +50,10 @@ class SeqNetBuffers:
         self.err = torch.zeros(4, dtype=torch.int32, device=device)    # ... and its timeout flag
 
 
-def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
-                    wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, persistent: bool) -> None:
-    """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0]:
-    time-batched torso (3 conv launches over all T*B frames) -> one input-projection GEMM for all steps -> the
-    recurrence (one persistent launch, or T launches of the EPI_LSTM GEMM) -> time-batched FC + dueling head.
-    Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
-    sequence-priority pass (dense frames, ``frame_off`` None)."""
+def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
+                      wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor) -> None:
+    """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over all T*B frames + ONE input-projection GEMM
+    for all steps (throughput-bound)."""
     N = T * B
     H.conv_fwd(1, frames, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, N, frame_off)
     H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
@@ -64,9 +61,15 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
     H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
     H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), buf.xg.view(N, 4 * Hd), N, 4 * Hd, 3136, bias=bsum,
            flags=H.EPI_OUT_F32, big=N >= 1024)
+
+
+def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers,
+                          persistent: bool) -> None:
+    """The recurrence from the state in buf.hs[0] / buf.cs[0] (one persistent launch, or T launches of the EPI_LSTM
+    GEMM; latency-bound) + time-batched FC and dueling head."""
+    N = T * B
     w_hh = wb.view("lstm.w_hh")
     if persistent:
-        # one launch for all T steps (csrc/hip/lstm_seq.hip) instead of T launches of the EPI_LSTM GEMM
         H.lstm_seq_fwd([(buf.xg, w_hh, buf.hs, buf.cs, buf.gates)], T, B, Hd, buf.sync, buf.err)
     else:
         for t in range(T):
@@ -77,10 +80,19 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
     H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
 
 
+def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
+                    wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, persistent: bool) -> None:
+    """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0].
+    Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
+    sequence-priority pass (dense frames, ``frame_off`` None)."""
+    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum)
+    seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent)
+
+
 class R2D2Engine:
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0, overlap: bool = True):
+                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 1):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = dev = torch.device(device)
         self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
@@ -124,6 +136,8 @@ class R2D2Engine:
         self.dcol2 = torch.zeros(NB * 81, 512, **bf)
         self.d1 = torch.zeros(NB * 400, 32, **bf)
         self.wgrad_splits = wgrad_splits
+        import os as _os
+        self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
@@ -147,9 +161,15 @@ class R2D2Engine:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
         r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
         fj = self.fj
-        with fj.fork(0):                                            # target net || online net (240 small LSTM launches)
+        # forward. The two nets are STAGGERED, not run side by side: the torso is throughput-bound, the recurrence is
+        # latency-bound (32 workgroups), so the target torso runs under the online recurrence and the two recurrences
+        # overlap only partly.
+        H.gather_state(r.h0, r.idx, None, self.on.hs[0])
+        H.gather_state(r.c0, r.idx, self.on.cs[0], None)
+        seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on)
+        with fj.fork(0):                                            # target net: queued behind the online torso
             self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
-        self._net_forward(self.Pb, self.P, self.on, self.bsum_on)
+        seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm)
         H.is_weights(r.prio, self.st, self.w)
         fj.join()
         H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,
@@ -167,38 +187,52 @@ class R2D2Engine:
             H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
         H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
-        # BPTT
+        # BPTT: a latency-bound chain of 2 small launches per step. Everything below the LSTM is row-wise independent
+        # (weight gradients accumulate with atomics), so the window is cut into time chunks and the torso backward of a
+        # chunk can run on a side stream as soon as the chain has passed it (bwd_chunks > 1). Measured on MI355X the
+        # heavy kernels slow the chain down by as much as they gain (4.13 / 4.16 / 4.36 / 4.81 ms per step for 1 / 3 /
+        # 5 / 8 chunks), so the default is ONE chunk: the torso backward on a side stream next to the LSTM
+        # weight-gradient GEMMs, after the chain.
         self.dh_rec.zero_()
         self.dc.zero_()
         w_hh = Pb.view("lstm.w_hh")
+        csz = (L + self.bwd_chunks - 1) // self.bwd_chunks
+        starts = set(range(0, L, csz))
         for t in range(T - 1, burn - 1, -1):
             k = t - burn
             H.lstm_bwd_point(self.dhs[k], self.dh_rec, self.dc, on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k])
             if t > burn:
-                H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=16, big=False)
+                H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
+            if k in starts:
+                with fj.fork(1):
+                    self._torso_backward(k, min(L, k + csz))
         dG = self.dG.view(NB, 4 * Hd)
-        a3 = on.act3[r0:]
-        with fj.fork(1):                                            # LSTM weight gradients || input-gradient chain
+        with fj.fork(0):                                            # LSTM weight gradients: need the whole window
             H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
             G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
-        with fj.fork(2):
-            H.gemm(H.TN, dG, a3, G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
-        H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), self.d3.view(NB, 3136), NB, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
-        sp = self.wgrad_splits
-        a2, a1 = on.act2[r0:], on.act1[r0:]
-        with fj.fork(0):
-            H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), NB, splits=sp)
-            H.colsum(self.d3, G.view("conv3.b"), NB * 49, 64)
-        self._dgrad(3, self.d3, Pb.view("conv3.w"), self.dcol3, a2, self.d2, NB)
-        with fj.fork(1):
-            H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), NB, splits=sp)
-            H.colsum(self.d2, G.view("conv2.b"), NB * 81, 64)
-        self._dgrad(2, self.d2, Pb.view("conv2.w"), self.dcol2, a1, self.d1, NB)
-        with fj.fork(2):
-            H.colsum(self.d1, G.view("conv1.b"), NB * 400, 32)
-        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), NB, frame_off=r.frame_off[r0:], splits=2 * sp)
+        H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
         fj.join()
+
+    def _torso_backward(self, k0: int, k1: int) -> None:
+        """Backward of W_ih (input side) + conv3..conv1 for the time steps [k0, k1) of the backward window."""
+        B, Hd, NB, r = self.B, self.Hd, self.NB, self.replay
+        G, Pb, on = self.G, self.Pb, self.on
+        r0 = self.burn * B
+        lo, hi, n = k0 * B, k1 * B, (k1 - k0) * B
+        dG = self.dG.view(NB, 4 * Hd)[lo:hi]
+        a3, a2, a1 = on.act3[r0 + lo:r0 + hi], on.act2[r0 + lo:r0 + hi], on.act1[r0 + lo:r0 + hi]
+        d3, d2, d1 = self.d3[lo * 49:hi * 49], self.d2[lo * 81:hi * 81], self.d1[lo * 400:hi * 400]
+        sp = max(8, self.wgrad_splits * n // NB)
+        H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
+        H.conv_wgrad(3, a2, d3, G.view("conv3.w"), n, splits=sp)
+        H.colsum(d3, G.view("conv3.b"), n * 49, 64)
+        self._dgrad(3, d3, Pb.view("conv3.w"), self.dcol3, a2, d2, n)
+        H.conv_wgrad(2, a1, d2, G.view("conv2.w"), n, splits=sp)
+        H.colsum(d2, G.view("conv2.b"), n * 81, 64)
+        self._dgrad(2, d2, Pb.view("conv2.w"), self.dcol2, a1, d1, n)
+        H.colsum(d1, G.view("conv1.b"), n * 400, 32)
+        H.conv_wgrad(1, r.frames, d1, G.view("conv1.w"), n, frame_off=r.frame_off[r0 + lo:r0 + hi], splits=2 * sp)
 
     @staticmethod
     def _dgrad(layer, dy, w, dcol, act_in, dx, n) -> None:

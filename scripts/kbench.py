@@ -86,7 +86,7 @@ def main():
             cases["conv1_fwd" + sfx] = (lambda d=d: H.conv_fwd(1, x, w1, b1, a1, F, direct=d >= 0), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
         cases["conv2_fwd" + sfx] = (lambda d=d: H.conv_fwd(2, a1, w2, b2, a2, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
         cases["conv3_fwd" + sfx] = (lambda d=d: H.conv_fwd(3, a2, w3, b3, a3, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
-    for v in (0, 2, 3):
+    for v in (0, 2, 3, 5, 6):
         cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
     hf = torch.zeros(F, 1024, device=DEV)
     for sp in (2, 4, 8):
@@ -95,7 +95,7 @@ def main():
     dh = bf(B, 1024, scale=0.01)
     gfc = torch.zeros(1024, 3136, device=DEV)
     d3 = torch.zeros(B, 3136, dtype=torch.bfloat16, device=DEV)
-    for v in (0, 2, 3):
+    for v in (0, 2, 5, 6):
         cases["fc1_dw_tn_v%d" % v] = (lambda v=v: H.gemm(H.TN, dh, a3[:B], gfc, 1024, 3136, B, flags=H.EPI_OUT_F32, big=v), 2 * B * 1024 * 3136, 4 * 1024 * 3136)
         cases["fc1_dx_nn_v%d" % v] = (lambda v=v: H.gemm(H.NN, dh, wfc, d3, B, 3136, 1024, mask=a3[:B], flags=H.EPI_MASK, big=v), 2 * B * 1024 * 3136, 2 * 1024 * 3136)
     d3v = bf(B * 49, 64, scale=0.01)
@@ -132,6 +132,11 @@ def main():
     xg_t, c0 = torch.randn(64, 2048, device=DEV), torch.zeros(64, 512, device=DEV)
     ho, co = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 512, device=DEV)
     cases["lstm_step"] = (lambda: H.lstm_step(hp, whh, xg_t, c0, ho, co, None), 2 * 64 * 2048 * 512, 0)
+    dGk = bf(64, 2048, scale=0.01)
+    dhr = torch.zeros(64, 512, device=DEV)
+    for v in (0, 2, 5):
+        for sp in (8, 16, 32):
+            cases["bptt_nn_v%d_s%d" % (v, sp)] = (lambda v=v, sp=sp: H.gemm(H.NN, dGk, whh, dhr, 64, 512, 2048, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=sp, big=v), 2 * 64 * 512 * 2048, 0)
     Ts = 120
     xgs = torch.randn(Ts, 64, 2048, device=DEV) * 0.3
     hss = torch.zeros(Ts + 1, 64, 512, dtype=torch.bfloat16, device=DEV)
