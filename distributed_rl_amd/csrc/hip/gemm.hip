@@ -591,12 +591,17 @@ DRL_API int drl_conv_fwd(int layer, const void* x, const long long* frame_off, i
 DRL_API int drl_conv_wgrad(int layer, const void* x, const long long* frame_off, int frames, const void* dy, float* dw,
                            int splits, hipStream_t s) {
     const int fl = EPI_OUT_F32 | EPI_ATOMIC;
+    const int variant = splits >> 16;          // tile variant in the high half (tuning hook), split count in the low half
+    splits &= 0xffff;
     if (layer == 1) {
         const int rows = frames * Conv1Op::OH * Conv1Op::OW;
         DenseOp A{(const bf16_t*)dy, 32, rows};
         const Epilogue ep = make_epi(dw, Conv1Op::K, nullptr, nullptr, 0, 1.0f / 255.0f, fl);
         if (frame_off) {
             Conv1OffOp B{x, frame_off, rows};
+            // wide-N tiles read every dY row once per workgroup instead of once per 64 weight columns
+            if (variant == 1) return launch<32, 256, 128, 1, 4, true, true, 2>(A, B, 32, Conv1Op::K, rows, splits, ep, s);
+            if (variant == 2) return launch<32, 128, 128, 1, 4, true, true, 2>(A, B, 32, Conv1Op::K, rows, splits, ep, s);
             return launch<32, 64, 128, 1, 4, true, true, 4>(A, B, 32, Conv1Op::K, rows, splits, ep, s);
         }
         Conv1Op B{x, nullptr, rows};

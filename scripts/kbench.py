@@ -108,6 +108,10 @@ def main():
         cases["conv1_wgrad_s%d" % sp] = (lambda sp=sp: H.conv_wgrad(1, x[:B], d1v, g1, B, splits=2 * sp), 2 * B * 400 * 32 * 256, B * 28224)
     dx2 = torch.zeros(B, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
     dx1 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    foff = (torch.arange(B, device=DEV, dtype=torch.int64) * 28224)
+    for v in (0, 1, 2):
+        for sp in (64, 128, 256):
+            cases["conv1_wgrad_off_v%d_s%d" % (v, sp)] = (lambda v=v, sp=sp: H.conv_wgrad(1, x, d1v, g1, B, frame_off=foff, splits=sp | (v << 16)), 2 * B * 400 * 32 * 256, B * 28224)
     dc3 = torch.zeros(B * 49, 576, dtype=torch.bfloat16, device=DEV)
     dc2 = torch.zeros(B * 81, 512, dtype=torch.bfloat16, device=DEV)
     cases["conv3_dcol"] = (lambda: H.conv_dcol(3, d3v, w3, dc3, B), 2 * B * 49 * 64 * 576, 2 * B * 49 * 576)
