@@ -54,6 +54,26 @@ def _worker(rank, world, port, out_dir):
     assert tot == 10.0 * sum(range(1, world + 1)) and n == 100 * sum(range(1, world + 1))
     assert dist.max_scalar(float(rank)) == world - 1
     dist.barrier()
+    # parameter sync by broadcast (RCCL on GPUs, gloo here): rank 0 = learner, rank 1 = an actor with a receiver thread
+    from distributed_rl_amd.transport.collective_params import CollectiveParams
+    import time
+    ch = CollectiveParams(pack.flat.numel(), src_rank=0)
+    if rank == 0:
+        assert ch.publish(torch.full_like(pack.flat, 3.0)) == 1
+        assert ch.publish(pack.flat.numpy() * 0 + 7.0) == 2
+        ch.close()
+    else:
+        seen, t0 = 0, time.time()
+        while seen < 2 and time.time() - t0 < 60:
+            got = ch.pull(seen)
+            if got is None:
+                time.sleep(0.01)
+                continue
+            seen, flat = got
+            assert flat.shape == (pack.flat.numel(),) and float(flat[0]) == (3.0 if seen == 1 else 7.0) and float(flat[-1]) == float(flat[0])
+        assert seen == 2 and ch.pull(2) is None
+        ch.close()
+    dist.barrier()
     dist.close()
     open(os.path.join(out_dir, "ok%d" % rank), "w").close()
 
