@@ -37,6 +37,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 #define NTHREADS 256
+#ifndef DRL_GEMM_STORE_FIRST
+#define DRL_GEMM_STORE_FIRST 1
+#endif
 
 enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16, EPI_REMAP = 32 };
 
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     static_assert(WM * WN == 4, "4 waves");
     static_assert(D >= 2 && D % 2 == 0, "ring depth");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;    // MFMA tiles per wave
+    constexpr bool STORE_FIRST = DRL_GEMM_STORE_FIRST;
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -374,6 +378,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
         constexpr int S = decltype(sc)::value;
         sa[S].load(aop, ra, m0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
         sb[S].load(bop, rb, n0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
+        if (STORE_FIRST) {   // tile cur+1 -> the other LDS buffer BEFORE the MFMA phase: its write latency hides under it
+            sa[(S + 1) % D].store(As((S + 1) & 1), tid);
+            sb[(S + 1) % D].store(Bs((S + 1) & 1), tid);
+        }
 #pragma unroll
         for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 af[TM], bf[TN];
@@ -388,8 +396,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, bf[j]),
                                                                         __builtin_bit_cast(mfma_bf16x8, af[i]), acc[i][j], 0, 0, 0);
         }
-        sa[(S + 1) % D].store(As((S + 1) & 1), tid);   // tile cur+1 (zeros past the end: never read)
-        sb[(S + 1) % D].store(Bs((S + 1) & 1), tid);
+        if (!STORE_FIRST) {
+            sa[(S + 1) % D].store(As((S + 1) & 1), tid);   // tile cur+1 (zeros past the end: never read)
+            sb[(S + 1) % D].store(Bs((S + 1) & 1), tid);
+        }
         __syncthreads();
     };
     int kt = kt0;
