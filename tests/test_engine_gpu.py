@@ -10,7 +10,7 @@ from distributed_rl_amd.models import DuelingDQN  # noqa: E402
 from distributed_rl_amd.ops import oracle  # noqa: E402
 
 
-def _setup(B=64, cap=1000, A=6, seed=0):
+def _setup(B=64, cap=1000, A=6, seed=0, rms_eps=None):
     from distributed_rl_amd.engine.apex import ApexEngine
     from distributed_rl_amd.replay.device_per import DevicePER
     torch.manual_seed(seed)
@@ -19,6 +19,12 @@ def _setup(B=64, cap=1000, A=6, seed=0):
         for p in model.parameters():
             p.copy_(p.to(torch.bfloat16).float())           # weights exactly representable in bf16
     cfg = ApexConfig(batch_size=B, target_update=10 ** 9)
+    if rms_eps is not None:
+        # trajectory-comparison tests: with the reference's eps = 1.5e-7 the first RMSprop steps are sign-like (a
+        # near-zero gradient whose sign flips with the order of float atomics moves a weight by ~4.5 lr), which turns
+        # harmless reduction-order noise into a visible parameter distance. A larger eps keeps the update proportional
+        # to the gradient, so equal schedules must agree tightly and a real race cannot hide behind that noise.
+        cfg.rms_eps = rms_eps
     rep = DevicePER(cap, "cuda", batch_size=B, seed=3)
     rep.fill_synthetic(cap - 100, n_action=A, seed=1)
     eng = ApexEngine(A, cfg, rep, "cuda", init_model=model, use_graph=False)
@@ -80,8 +86,8 @@ def test_apex_engine_step_matches_oracle():
 
 
 def test_apex_engine_graph_equals_eager_and_learns():
-    _, cfg, rep, e1 = _setup(seed=1)
-    _, _, rep2, e2 = _setup(seed=1)
+    _, cfg, rep, e1 = _setup(seed=1, rms_eps=1e-2)
+    _, _, rep2, e2 = _setup(seed=1, rms_eps=1e-2)
     e2.use_graph = True
     for _ in range(7):
         e1.step()
@@ -92,15 +98,18 @@ def test_apex_engine_graph_equals_eager_and_learns():
     assert e1.stats()["step"] == 7 and e2.stats()["step"] == 7
     a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
     assert torch.isfinite(a).all()
-    # same RNG stream, same data; float atomics reorder, and early RMSprop steps are sign-like (a near-zero gradient
-    # that flips sign moves a weight by ~4.5 lr): loose bound, tight loss agreement
-    assert (a - b).norm() / a.norm() < 3e-3
+    dist_ab = float((a - b).norm() / a.norm())
+    print("graph-vs-eager relative parameter distance: %.3e" % dist_ab)
+    assert dist_ab < 2e-5                                # same RNG stream, same data; only float atomics reorder
     assert e2.stats()["loss"] == pytest.approx(e1.stats()["loss"], rel=2e-2)
-    # loss goes down on a fixed tiny replay (window means: single PER batches are noisy)
+    # loss goes down on a fixed tiny replay with the reference's optimizer settings (window means: single PER batches
+    # are noisy)
+    _, _, rep3, e3 = _setup(seed=1)
+    e3.use_graph = True
     losses = []
     for i in range(240):
-        e2.step()
-        losses.append(e2.stats()["loss"])
+        e3.step()
+        losses.append(e3.stats()["loss"])
     assert all(l == l for l in losses)
     assert sum(losses[-40:]) < sum(losses[:40]), (losses[:40], losses[-40:])
 
@@ -119,8 +128,8 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
     dist = Dist()
     try:
         assert dist.enabled and dist.world_size == 1
-        _, cfg, rep, e1 = _setup(seed=2)
-        _, _, rep2, e2 = _setup(seed=2)
+        _, cfg, rep, e1 = _setup(seed=2, rms_eps=1e-2)
+        _, _, rep2, e2 = _setup(seed=2, rms_eps=1e-2)
         e1.use_graph = True
         e2.use_graph = True
         e2.dist = dist
@@ -131,28 +140,26 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
         assert e1._graphs[0] == "one" and e2._graphs[0] == "overlap"
         assert e1.stats()["step"] == e2.stats()["step"] == 8
         a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
-        # same data and RNG stream; float atomics reorder, and early RMSprop steps are sign-like (a near-zero gradient
-        # that flips sign moves a weight by ~4.5 lr), hence the loose bound
-        assert torch.isfinite(b).all() and (a - b).norm() / a.norm() < 3e-3
+        assert torch.isfinite(b).all() and (a - b).norm() / a.norm() < 2e-5     # only float atomics reorder
         assert e2.stats()["loss"] == pytest.approx(e1.stats()["loss"], rel=2e-2)
         # eager flavour of the same schedule
-        _, _, rep3, e3 = _setup(seed=2)
+        _, _, rep3, e3 = _setup(seed=2, rms_eps=1e-2)
         e3.dist = dist
         for _ in range(8):
             e3.step()
         torch.cuda.synchronize()
-        assert (a - e3.P.flat.cpu()).norm() / a.norm() < 3e-3
+        assert (a - e3.P.flat.cpu()).norm() / a.norm() < 2e-5
         # collectives captured INTO one graph; without the env override a cross-rank trial decides
         monkeypatch.delenv("DRL_GRAPH_COLLECTIVES")
         assert dist.graph_collectives is True                   # RCCL captures fine on this stack
-        _, _, rep4, e4 = _setup(seed=2)
+        _, _, rep4, e4 = _setup(seed=2, rms_eps=1e-2)
         e4.use_graph = True
         e4.dist = dist
         for _ in range(6):
             e4.step()
         torch.cuda.synchronize()
         assert e4._graphs[0] == "one" and e4.stats()["step"] == 8
-        assert (a - e4.P.flat.cpu()).norm() / a.norm() < 3e-3
+        assert (a - e4.P.flat.cpu()).norm() / a.norm() < 2e-5
     finally:
         dist.close()
 
