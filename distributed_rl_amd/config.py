@@ -118,6 +118,7 @@ class LaunchConf:
     actor_device: str = ""
     transport: str = "shm"           # shm | redis | inproc  (new key)
     num_envs: int = 1                # envs per actor process (new key)
+    learner_gpus: int = 1            # data-parallel learner ranks on this node, one per GPU (new key)
     run_dir: str = ""                # where shm names / heartbeats / logs live (new key)
     extra: Dict[str, str] = field(default_factory=dict)
 

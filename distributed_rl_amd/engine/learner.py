@@ -148,7 +148,7 @@ class HipLearner:
                 t_last, n_last = now, t
                 if self.heartbeat is not None:
                     self.heartbeat.tick(t)
-            if t % cfg.save_timing == 0:
+            if t % cfg.save_timing == 0 and (self.dist is None or self.dist.rank == 0):        # one writer
                 self.save(save_model_dir)
             self.step += 1
         torch.cuda.synchronize(self.device)
@@ -158,8 +158,14 @@ class HipLearner:
 def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
     from ..parallel.dist import Dist
     dist = Dist(device=device) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+    seed_ = (args.seed or 0) + (dist.rank if dist is not None else 0)      # every shard samples its own stream
     learner = HipLearner(args.algorithm, n_action, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb, dist=dist,
-                         seed=args.seed or 0)
+                         seed=seed_)
+    if dist is not None:                                                   # identical initial weights on every rank
+        dist.broadcast_flat(learner.engine.P.flat)
+        from ..ops import hip as H
+        H.cast_bf16(learner.engine.P.flat, learner.engine.Pb.flat)
+        learner.engine.sync_target()
     if args.resume:
         learner.resume(args.resume)
     learner.publish()

@@ -37,15 +37,21 @@ def build_commands(conf, n_actors: int, server: str, run_id: str, extra_learner:
         common += ["-v", visdom_server]
     if conf.visdom:
         cmds["visdom"] = [python, "-m", "visdom.server", "-logging_level", "WARNING"]       # run.sh:20-24
+    n_ranks = max(1, int(conf.learner_gpus))
     if conf.learner:
-        c = [python, os.path.join(ROOT, "learner_node.py")] + common
+        if n_ranks > 1:      # data-parallel learners: one rank per GPU, rendezvous on loopback
+            c = [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
+                 "127.0.0.1", "--master-port", str(29400 + (abs(hash(run_id)) % 500)),
+                 os.path.join(ROOT, "learner_node.py")] + common
+        else:
+            c = [python, os.path.join(ROOT, "learner_node.py")] + common
         if conf.actor_device:
             c += ["-d", conf.actor_device]                                                   # run.sh:27-33
         cmds["learner"] = c + extra_learner
     if conf.actor:
         for i in range(1, n_actors + 1):                                                     # run.sh:36-42
             cmds["actor_%d" % i] = [python, os.path.join(ROOT, "actor_node.py"), "-n", str(i), "-t", str(n_actors)] + \
-                common + ["--num-envs", str(conf.num_envs)] + extra_actor
+                common + ["--num-envs", str(conf.num_envs), "--learner-ranks", str(n_ranks)] + extra_actor
     return cmds
 
 

@@ -171,7 +171,7 @@ class Learner:
                     t_last, n_last = now, t
             if t % cfg.target_update == 0:
                 self.target.load_state_dict(self.policy.state_dict())                          # learner.py:93-95
-            if t % cfg.save_timing == 0:
+            if t % cfg.save_timing == 0 and (self.dist is None or self.dist.rank == 0):        # one writer
                 save_checkpoint(save_model_dir, t, self.policy, self.target, self.opt)         # learner.py:96-98
             if self.heartbeat is not None:
                 self.heartbeat.tick(t)

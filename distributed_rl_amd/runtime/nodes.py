@@ -33,6 +33,12 @@ def _common(parser):
     parser.add_argument('--device', type=str, default='', help="'' = cuda if available else cpu.")
 
 
+def shard_run_id(run_id: str, rank: int, world: int) -> str:
+    """Data-parallel learners: every learner rank owns its OWN experience ring + parameter register (a replay shard in
+    its own HBM fed by its own actors); rank 0 keeps the plain run id so single-learner tools keep working."""
+    return run_id if world <= 1 or rank == 0 else "%s_r%d" % (run_id, rank)
+
+
 def _device(name: str) -> torch.device:
     if name:
         return torch.device(name)
@@ -58,6 +64,8 @@ def actor_main(argv=None) -> int:
     parser.add_argument('--param-period', type=int, default=None)
     parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
                         help='hip = batched gfx950 inference engine (Ape-X and R2D2; needs a GPU).')
+    parser.add_argument('--learner-ranks', type=int, default=int(os.environ.get('DRL_LEARNER_RANKS', '1')),
+                        help='Number of data-parallel learner ranks; actor i feeds the shard of rank (i-1) %% ranks.')
     _common(parser)
     args = parser.parse_args(argv)
     from .actor import Actor
@@ -65,7 +73,17 @@ def actor_main(argv=None) -> int:
     cfg = make_config(args.algorithm, actor_batch=args.actor_batch, actor_param_period=args.param_period)
     env = envs.make_vec(args.env, args.num_envs, seed=args.seed)
     metrics = make_metrics("actor_%d" % args.no, args.visdomserver, args.log_dir, args.quiet)
-    exp, par = connect(args.transport, args.run_id, create=False, host=args.redisserver)
+    shard = shard_run_id(args.run_id, (args.no - 1) % max(1, args.learner_ranks), args.learner_ranks)
+    import time as _time
+    t_end = _time.time() + float(os.environ.get("DRL_CONNECT_TIMEOUT", "120"))
+    while True:                    # the learner (possibly several ranks under torch.distributed.run) creates the segments
+        try:
+            exp, par = connect(args.transport, shard, create=False, host=args.redisserver)
+            break
+        except OSError:
+            if _time.time() > t_end:
+                raise
+            _time.sleep(0.25)
     hb = _heartbeat(args, "actor", args.no)
     if args.algorithm == 'ape_x':
         engine = None
@@ -122,8 +140,12 @@ def learner_main(argv=None) -> int:
     cfg = make_config(args.algorithm, batch_size=args.batch_size, start_memory_size=args.start_memory_size,
                       save_timing=args.save_timing, target_update=args.target_update)
     n_action = envs.n_action_of(args.env)             # the reference builds a whole env just for this (learner_node.py:20)
-    metrics = make_metrics("learner", args.visdomserver, args.log_dir, args.quiet)
-    exp, par = connect(args.transport, args.run_id, create=True, host=args.redisserver,
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and device.type == "cuda":
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    metrics = make_metrics("learner" if rank == 0 else "learner_r%d" % rank, args.visdomserver, args.log_dir,
+                           args.quiet or rank > 0)
+    exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=True, host=args.redisserver,
                        n_slots=args.ring_slots, slot_bytes=args.ring_slot_mb << 20)
     hb_table, hb = None, None
     if args.transport == 'shm':
@@ -132,7 +154,7 @@ def learner_main(argv=None) -> int:
             hb_table = HeartbeatTable(shm_names(args.run_id)[2], create=False)
         except OSError:
             hb_table = HeartbeatTable(shm_names(args.run_id)[2], create=True)
-        hb = hb_table.register("learner", 0)
+        hb = hb_table.register("learner", rank)
     engine = args.engine
     if engine == 'auto':
         engine = 'hip' if device.type == 'cuda' else 'torch'
@@ -149,8 +171,16 @@ def learner_main(argv=None) -> int:
             target = DuelingLSTMDQN(n_action, cfg.batch_size, cfg.burn_in, cfg.nstep).to(device)
             opt = optim.Adam(model.parameters(), lr=cfg.lr, eps=cfg.adam_eps)                             # learner_node.py:40
         start = load_checkpoint(args.resume, model, target, opt) if args.resume else 0
+        dist = None
+        if world > 1:
+            from ..parallel.dist import Dist
+            dist = Dist(device=device)
+            with torch.no_grad():                          # identical initial weights on every rank
+                for p_ in model.parameters():
+                    dist.broadcast_flat(p_.data)
+                target.load_state_dict(model.state_dict())
         learner = Learner(model, target, opt, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb,
-                          sync_target=not args.resume)
+                          sync_target=not args.resume, dist=dist)
         learner.publish()
         try:
             learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir, start_step=start)

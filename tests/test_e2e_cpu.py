@@ -97,3 +97,21 @@ def test_run_sh_two_actors(tmp_path, run_id):
     sd = torch.load(save / "model_5.pth", weights_only=True)
     assert tuple(sd["adv1.weight"].shape) == (512, 3136)
     assert not glob.glob("/dev/shm/drl_%s_*" % run_id)             # segments cleaned up
+
+
+def test_run_sh_two_data_parallel_learners(tmp_path, run_id):
+    """`learner_gpus=2` in the conf: the launcher starts the learner under torch.distributed.run (2 ranks, gloo on CPU),
+    every rank owns its own experience ring + replay shard, actor i feeds rank (i-1) % 2, gradients are all-reduced and
+    only rank 0 writes checkpoints."""
+    conf = tmp_path / "dp.conf"
+    conf.write_text("actor=true\nlearner=true\nvisdom=false\nalgorithm=ape_x\nredis_server=localhost\n"
+                    "visdom_server=localhost\nactor_device=cpu\nlearner_gpus=2\n")
+    save = tmp_path / "models"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DRL_NUM_ENVS="2")
+    cmd = [os.path.join(ROOT, "run.sh"), "2", str(conf), "", "--run-id", run_id, "--timeout", "280",
+           "--learner-args", "--max-steps 6 --batch-size 16 --start-memory-size 32 --save-timing 5 --save-dir %s --quiet --device cpu --engine torch" % save,
+           "--actor-args", "--quiet --device cpu --actor-batch 16"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=330)
+    assert "learner exited with 0" in r.stdout, r.stdout[-3000:]
+    assert os.path.exists(save / "model_5.pth"), r.stdout[-3000:]
+    assert not glob.glob("/dev/shm/drl_%s_*" % run_id)             # both shards' segments cleaned up
