@@ -154,6 +154,16 @@ def main(argv=None) -> int:
         teardown()
         if hb_table is not None:
             hb_table.close()
+        if conf.transport == "shm":
+            # a learner that was terminated could not unlink its segments: sweep every shard's names (best effort)
+            n_ranks = max(1, int(conf.learner_gpus))
+            for r in range(n_ranks):
+                rid = run_id if r == 0 else "%s_r%d" % (run_id, r)
+                for name in shm_names(rid):
+                    try:
+                        os.unlink("/dev/shm" + name)
+                    except OSError:
+                        pass
     return rc
 
 
