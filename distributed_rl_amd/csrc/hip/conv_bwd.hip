@@ -5,6 +5,7 @@
 //     fused so the result is directly d(pre-activation) of the previous layer;
 //   * column sums of dY for the bias gradients.
 #include "common.h"
+#include "colsum_body.h"
 
 template <int H, int W, int C, int KS, int S>
 __global__ __launch_bounds__(256) void k_col2im(const bf16_t* __restrict__ dcol, const bf16_t* __restrict__ act_in,
@@ -52,37 +53,11 @@ __global__ __launch_bounds__(256) void k_col2im(const bf16_t* __restrict__ dcol,
     }
 }
 
-// db[n] += sum_m dY[m][n]. The matrix is walked as a flat stream of 16-B chunks (8 bf16 columns): with N/8 dividing
-// 256 every thread stays on the same 8 columns, so it accumulates 8 floats in registers over its whole slice, the
-// block folds its 256 partial rows through LDS and issues N atomics. grid = ceil(chunks / cpb), block = 256.
+// db[n] += sum_m dY[m][n]: see colsum_body.h. grid = ceil(chunks / cpb), block = 256.
 __global__ __launch_bounds__(256) void k_colsum(const bf16_t* __restrict__ dy, long long total, int NC8, int cpb,
                                                float* __restrict__ db) {
-    __shared__ float red[256][9];
-    const int tid = threadIdx.x;
-    const long long c0 = (long long)blockIdx.x * cpb, c1 = min(total, c0 + cpb);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto add = [&](const uint4& v) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { acc[2 * t] += __uint_as_float(w[t] << 16); acc[2 * t + 1] += __uint_as_float(w[t] & 0xffff0000u); }
-    };
-    long long i = c0 + tid;
-    for (; i + 768 < c1; i += 1024) {          // 4 independent 16-B loads in flight per thread
-        const uint4 v0 = reinterpret_cast<const uint4*>(dy)[i], v1 = reinterpret_cast<const uint4*>(dy)[i + 256];
-        const uint4 v2 = reinterpret_cast<const uint4*>(dy)[i + 512], v3 = reinterpret_cast<const uint4*>(dy)[i + 768];
-        add(v0); add(v1); add(v2); add(v3);
-    }
-    for (; i < c1; i += 256) add(reinterpret_cast<const uint4*>(dy)[i]);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) red[tid][t] = acc[t];
-    __syncthreads();
-    const int N = NC8 * 8, reps = 256 / NC8;
-    for (int col = tid; col < N; col += 256) {
-        const int g = col >> 3, e = col & 7;
-        float sum = 0.f;
-        for (int j = 0; j < reps; ++j) sum += red[j * NC8 + g][e];
-        atomicAdd(&db[col], sum);
-    }
+    __shared__ float red[256 * 9];
+    colsum_block(dy, total, NC8, cpb, db, blockIdx.x, red);
 }
 
 // out[r][c] = a[r][c] * (mask[r][c] > 0)   (standalone ReLU backward, bf16)
@@ -122,10 +97,7 @@ DRL_API int drl_col2im(int layer, const void* dcol, const void* act_in, void* dx
 DRL_API int drl_colsum(const void* dy, int M, int N, float* db, hipStream_t s) {
     if (M <= 0 || N < 8 || N > 2048 || (N & (N - 1))) return -1;   // N/8 must divide 256
     const long long total = (long long)M * (N / 8);
-    // few blocks on purpose: same-address fp32 atomics serialise in L2 (~35 ns each on MI355X), so the number of
-    // blocks, not the bytes read, sets the time of this kernel
-    long long cpb = ((total + 127) / 128 + 255) / 256 * 256;
-    if (cpb < 1024) cpb = 1024;
+    const long long cpb = colsum_cpb(total);
     k_colsum<<<(unsigned)((total + cpb - 1) / cpb), 256, 0, s>>>((const bf16_t*)dy, total, N / 8, (int)cpb, db);
     return (int)hipGetLastError();
 }

@@ -23,6 +23,8 @@
 //   * Epilogue fuses: x scale (uint8 frames: 1/255), + bias, ReLU, ReLU-backward mask, bf16 / f32 store, or f32
 //     atomic accumulation for split-K weight gradients.
 #include "common.h"
+#include "colsum_body.h"
+#include "head_bwd_body.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -324,13 +326,16 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
 //   D   : depth of the register prefetch ring (even): while tile k is multiplied out of LDS, the global loads of
 //         tiles k+1 .. k+D-1 are in flight in D-1 register sets.
 // ---------------------------------------------------------------------------------------------------
+// The body is a device function of the tile coordinates (bx, by, bz) so that it runs both as its own kernel (k_gemm) and
+// as one of several bodies of a horizontally fused launch (k_multi, below).
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
-__global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
-    constexpr bool CLASSES = AOp::HAS_CLASS;     // blockIdx.z = stride-parity class of an implicit dgrad (no split-K)
+__device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep, int bx, int by,
+                                          int bz, uint8_t* smem) {
+    constexpr bool CLASSES = AOp::HAS_CLASS;     // bz = stride-parity class of an implicit dgrad (no split-K)
     static_assert(AOp::HAS_CLASS == BOp::HAS_CLASS, "both operands must agree on classes");
     if constexpr (CLASSES) {
-        aop.set_class(blockIdx.z);
-        bop.set_class(blockIdx.z);
+        aop.set_class(bz);
+        bop.set_class(bz);
         ep.rm_py = aop.py;
         ep.rm_px = aop.px;
     }
@@ -340,15 +345,14 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
     constexpr bool STORE_FIRST = DRL_GEMM_STORE_FIRST;
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     auto As = [&](int i) -> uint8_t* { return smem + i * (A_BYTES + B_BYTES); };
     auto Bs = [&](int i) -> uint8_t* { return smem + i * (A_BYTES + B_BYTES) + A_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int nkt = (Kc + BKT - 1) / BKT;
-    const int kt0 = CLASSES ? 0 : blockIdx.z * kt_per, kt1 = min(kt0 + kt_per, nkt);
+    const int kt0 = CLASSES ? 0 : bz * kt_per, kt1 = min(kt0 + kt_per, nkt);
     if (kt0 >= kt1) return;
 
     f32x4 acc[TM][TN];
@@ -485,8 +489,14 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int
 }
 
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
-static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s,
-                  int classes = 0) {
+__global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(aop, bop, Mo, No, Kc, kt_per, ep, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// grid / split / LDS plan shared by the stand-alone launch and the fused launches; returns 0 or a negative error
+template <int BM, int BN, int BKT>
+static int plan_gemm(int Mo, int No, int Kc, int splits, const Epilogue& ep, int classes, int* kt_per_out, dim3* grid, size_t* lds) {
     if (No % BN != 0 || Mo <= 0 || Kc <= 0) return -2;
     const int nkt = (Kc + BKT - 1) / BKT;
     if (splits < 1) splits = 1;
@@ -495,9 +505,20 @@ static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits
     splits = (nkt + kt_per - 1) / kt_per;
     if (classes > 0) { kt_per = nkt; splits = classes; }     // grid.z = parity classes, each runs the whole K range
     if (splits > 1 && !classes && !(ep.flags & EPI_ATOMIC)) return -3;
-    dim3 grid(No / BN, (Mo + BM - 1) / BM, splits);
-    size_t lds = 2 * (size_t)(BM + BN) * BKT * 2;
-    if ((ep.flags & EPI_ATOMIC) && lds < (size_t)BM * (BN + 4) * 4) lds = (size_t)BM * (BN + 4) * 4;
+    *grid = dim3(No / BN, (Mo + BM - 1) / BM, splits);
+    *lds = 2 * (size_t)(BM + BN) * BKT * 2;
+    if ((ep.flags & EPI_ATOMIC) && *lds < (size_t)BM * (BN + 4) * 4) *lds = (size_t)BM * (BN + 4) * 4;
+    *kt_per_out = kt_per;
+    return 0;
+}
+
+template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
+static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s,
+                  int classes = 0) {
+    int kt_per;
+    dim3 grid;
+    size_t lds;
+    if (int rc = plan_gemm<BM, BN, BKT>(Mo, No, Kc, splits, ep, classes, &kt_per, &grid, &lds)) return rc;
     auto kern = k_gemm<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>;
     if (lds > 64 * 1024) {
         static bool once = false;
@@ -674,4 +695,205 @@ DRL_API int drl_lstm_step(const void* h_prev, const void* w_hh, const float* xg,
     ep.xg = xg; ep.ldxg = 4LL * H; ep.c_prev = c_prev; ep.c_out = c_out; ep.h_out = (bf16_t*)h_out; ep.gates_out = (bf16_t*)gates_out;
     DenseOp A{(const bf16_t*)h_prev, H, M}, B{(const bf16_t*)w_hh, H, 4 * H};
     return launch<64, 64, 256, 2, 2, false, false, 2>(A, B, M, 4 * H, H, 1, ep, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Horizontally fused backward launches
+// ---------------------------------------------------------------------------------------------------
+// The backward of a layer is two or three INDEPENDENT kernels (input gradient, weight gradient, bias gradient), each
+// too small to fill 256 CUs. Run on side streams they overlap, but every fork / join of a replayed hipGraph costs
+// 5-11 us of cross-queue signalling on MI355X (profiles/apex_step_timeline_v3.txt) - a third of the kernels' own time.
+// k_multi runs up to four such bodies as ONE launch: workgroup ranges [0,e0) [e0,e1) [e1,e2) [e2,grid) execute body
+// 0..3; the launch allocates max(VGPR) / max(LDS) of its bodies. Dependent launches in one queue start back to back.
+template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
+struct GemmBody {
+    struct Args { AOp a; BOp b; int Mo, No, Kc, kt_per, gx, gy; Epilogue ep; };
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        const int bx = block % g.gx, r = block / g.gx, by = r % g.gy, bz = r / g.gy;
+        gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(g.a, g.b, g.Mo, g.No, g.Kc, g.kt_per, g.ep, bx, by, bz, smem);
+    }
+    // fills ``g``; returns the number of workgroups (or a negative error) and raises *lds to what this body needs
+    static int plan(Args& g, const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, int classes, size_t* lds) {
+        dim3 grid;
+        size_t need;
+        int kt_per;
+        if (int rc = plan_gemm<BM, BN, BKT>(Mo, No, Kc, splits, ep, classes, &kt_per, &grid, &need)) return rc;
+        g.a = a; g.b = b; g.Mo = Mo; g.No = No; g.Kc = Kc; g.kt_per = kt_per; g.gx = grid.x; g.gy = grid.y; g.ep = ep;
+        if (need > *lds) *lds = need;
+        return (int)(grid.x * grid.y * grid.z);
+    }
+};
+
+struct ColsumBody {
+    struct Args { const bf16_t* dy; long long total; int NC8, cpb; float* db; };
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        colsum_block(g.dy, g.total, g.NC8, g.cpb, g.db, block, reinterpret_cast<float*>(smem));
+    }
+    static int plan(Args& g, const void* dy, long long M, int N, float* db, size_t* lds) {
+        if (M <= 0 || N < 8 || N > 2048 || (N & (N - 1))) return -1;
+        g.dy = (const bf16_t*)dy; g.total = M * (N / 8); g.NC8 = N / 8; g.cpb = (int)colsum_cpb(g.total); g.db = db;
+        if (*lds < 256 * 9 * 4) *lds = 256 * 9 * 4;
+        return (int)((g.total + g.cpb - 1) / g.cpb);
+    }
+};
+
+struct HeadDwBody {
+    struct Args { const float* dq; const bf16_t* h; int M, A; float *gw_adv, *gb_adv, *gw_val, *gb_val; };
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        head_dw_block(g.dq, g.h, g.M, g.A, g.gw_adv, g.gb_adv, g.gw_val, g.gb_val, block & 3, block >> 2, reinterpret_cast<float*>(smem));
+    }
+    static int plan(Args& g, const float* dq, const void* h, int M, int A, float* gw_adv, float* gb_adv, float* gw_val, float* gb_val,
+                    size_t* lds) {
+        if (!dq) return 0;
+        if (M <= 0 || A <= 0 || A > HEAD_MAX_A) return -1;
+        g.dq = dq; g.h = (const bf16_t*)h; g.M = M; g.A = A; g.gw_adv = gw_adv; g.gb_adv = gb_adv; g.gw_val = gw_val; g.gb_val = gb_val;
+        if (*lds < DW_ROWS * (HEAD_MAX_A + 1) * 4) *lds = DW_ROWS * (HEAD_MAX_A + 1) * 4;
+        return 4 * ((M + DW_ROWS - 1) / DW_ROWS);
+    }
+};
+
+struct NoBody {
+    struct Args { int unused; };
+    static __device__ __forceinline__ void run(const Args&, int, uint8_t*) {}
+};
+
+template <class B0, class B1, class B2, class B3>
+__global__ __launch_bounds__(NTHREADS) void k_multi(typename B0::Args a0, typename B1::Args a1, typename B2::Args a2,
+                                                    typename B3::Args a3, int e0, int e1, int e2) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int b = blockIdx.x;
+    if (b < e0) B0::run(a0, b, smem);
+    else if (b < e1) B1::run(a1, b - e0, smem);
+    else if (b < e2) B2::run(a2, b - e1, smem);
+    else B3::run(a3, b - e2, smem);
+}
+
+template <class B0, class B1, class B2, class B3>
+static int launch_multi(const typename B0::Args& a0, int n0, const typename B1::Args& a1, int n1, const typename B2::Args& a2, int n2,
+                        const typename B3::Args& a3, int n3, size_t lds, hipStream_t s) {
+    if (n0 < 0) return n0;
+    if (n1 < 0) return n1;
+    if (n2 < 0) return n2;
+    if (n3 < 0) return n3;
+    if (lds > 64 * 1024) return -6;
+    const int total = n0 + n1 + n2 + n3;
+    if (total <= 0) return -1;
+    k_multi<B0, B1, B2, B3><<<total, NTHREADS, lds, s>>>(a0, a1, a2, a3, n0, n0 + n1, n0 + n1 + n2);
+    return (int)hipGetLastError();
+}
+
+// ---- fused FC backward: dX = relu'(x) * (dY . W), dW = dY^T . x, db = colsum(dY) [+ dueling-head weight grads] ----------
+// dY [M][N] bf16, x [M][K] bf16 (the layer's input: operand of dW and ReLU mask of dX), W [N][K] bf16, dW [N][K] f32
+// (overwritten), db [N] f32 (accumulated: zeroed by the caller), dX [M][K] bf16. dq != null adds the weight gradients of
+// the dueling head (head.hip, k_head_bwd_dw) on hq = the head's input [M][1024] as a fourth body.
+template <int DXD, int DWD, bool DW_FIRST>
+static int fc_bwd_launch(const void* dy, const void* x, const void* w, float* dw, float* db, void* dx, int M, int N, int K,
+                         const float* dq, const void* hq, int A, float* gw_adv, float* gb_adv, float* gw_val, float* gb_val,
+                         hipStream_t s) {
+    typedef GemmBody<64, 64, 64, 2, 2, false, true, DXD, DenseOp, DenseOp> DX;
+    typedef GemmBody<64, 64, 64, 2, 2, true, true, DWD, DenseOp, DenseOp> DW;
+    size_t lds = 0;
+    typename DX::Args ax; typename DW::Args aw; ColsumBody::Args ac; HeadDwBody::Args ah;
+    const bf16_t* pdy = (const bf16_t*)dy;
+    const int nx = DX::plan(ax, DenseOp{pdy, N, M}, DenseOp{(const bf16_t*)w, K, N}, M, K, N, 1,
+                            make_epi(dx, K, nullptr, x, K, 1.0f, EPI_MASK), 0, &lds);
+    const int nw = DW::plan(aw, DenseOp{pdy, N, M}, DenseOp{(const bf16_t*)x, K, M}, N, K, M, 1,
+                            make_epi(dw, K, nullptr, nullptr, 0, 1.0f, EPI_OUT_F32), 0, &lds);
+    const int nc = ColsumBody::plan(ac, dy, M, N, db, &lds);
+    const int nh = HeadDwBody::plan(ah, dq, hq, M, A, gw_adv, gb_adv, gw_val, gb_val, &lds);
+    if (DW_FIRST) return launch_multi<DW, DX, ColsumBody, HeadDwBody>(aw, nw, ax, nx, ac, nc, ah, nh, lds, s);
+    return launch_multi<DX, DW, ColsumBody, HeadDwBody>(ax, nx, aw, nw, ac, nc, ah, nh, lds, s);
+}
+
+DRL_API int drl_fc_bwd(const void* dy, const void* x, const void* w, float* dw, float* db, void* dx, int M, int N, int K,
+                       const float* dq, const void* hq, int A, float* gw_adv, float* gb_adv, float* gw_val, float* gb_val,
+                       int variant, hipStream_t s) {
+    if ((N & 7) || (K & 7) || (N % 64) || M <= 0) return -4;
+    if ((long long)M * K >= (1LL << 32) || (long long)N * K >= (1LL << 32) || (long long)M * N >= (1LL << 32)) return -8;
+#define FCB(a, b, c) return fc_bwd_launch<a, b, c>(dy, x, w, dw, db, dx, M, N, K, dq, hq, A, gw_adv, gb_adv, gw_val, gb_val, s)
+    switch (variant) {        // ring depths of the dX / dW bodies and their order (tuning hook, see docs/DESIGN.md)
+        case 0: FCB(4, 4, false);
+        case 1: FCB(4, 2, false);
+        case 2: FCB(2, 2, false);
+        case 3: FCB(4, 4, true);
+        case 4: FCB(4, 2, true);
+        case 5: FCB(2, 2, true);
+    }
+#undef FCB
+    return -7;
+}
+
+// ---- fused conv backward: dX (implicit dgrad, layers 2/3), dW (split-K atomics into a ZEROED buffer), db ---------------
+// x = the layer's forward input (layer 1: uint8 frames, optionally through frame_off; layers 2/3: NHWC bf16 activation,
+// which is also the ReLU mask of dX). dY = d(pre-activation) of this layer's output, NHWC bf16.
+template <class WG, class BOp>
+static int conv_bwd_12(const BOp& B, int cout, int kdim, float scale, const void* dy, float* dw, float* db, int splits, hipStream_t s) {
+    size_t lds = 0;
+    typename WG::Args aw; ColsumBody::Args ac;
+    const int nw = WG::plan(aw, DenseOp{(const bf16_t*)dy, cout, B.rows}, B, cout, kdim, B.rows, splits,
+                            make_epi(dw, kdim, nullptr, nullptr, 0, scale, EPI_OUT_F32 | EPI_ATOMIC), 0, &lds);
+    const int nc = ColsumBody::plan(ac, dy, B.rows, cout, db, &lds);
+    NoBody::Args none{0};
+    return launch_multi<WG, ColsumBody, NoBody, NoBody>(aw, nw, ac, nc, none, 0, none, 0, lds, s);
+}
+
+template <int H, int W, int KS, int S, int CI, int CO, int BM, int BN, int WM, int WN, class COp, int WBK, int WD, bool WG_FIRST>
+static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, float* dw, float* db, void* dx, int splits, hipStream_t s) {
+    typedef DgradOp<H, W, KS, S, CO> AOp;
+    typedef WdgradOp<KS, S, CI, CO> BOp;
+    typedef GemmBody<BM, BN, 64, WM, WN, false, true, 2, AOp, BOp> DG;
+    typedef GemmBody<64, 64, WBK, 2, 2, true, true, WD, DenseOp, COp> WG;
+    const int M = frames * AOp::HC * AOp::WC;
+    if ((long long)frames * AOp::OH * AOp::OW * CO >= (1LL << 40)) return -8;
+    size_t lds = 0;
+    typename DG::Args ad; typename WG::Args aw; ColsumBody::Args ac;
+    Epilogue ep = make_epi(dx, CI, nullptr, x, CI, 1.0f, EPI_MASK | EPI_REMAP);
+    ep.rm_hc = AOp::HC; ep.rm_wc = AOp::WC; ep.rm_s = S; ep.rm_h = H; ep.rm_w = W;
+    const int nd = DG::plan(ad, AOp{(const bf16_t*)dy, M, 0, 0}, BOp{(const bf16_t*)w, 0, 0}, M, CI, AOp::K, 1, ep, S * S, &lds);
+    COp B{x, nullptr, frames * COp::OH * COp::OW};
+    const int nw = WG::plan(aw, DenseOp{(const bf16_t*)dy, CO, B.rows}, B, CO, COp::K, B.rows, splits,
+                            make_epi(dw, COp::K, nullptr, nullptr, 0, 1.0f, EPI_OUT_F32 | EPI_ATOMIC), 0, &lds);
+    const int nc = ColsumBody::plan(ac, dy, B.rows, CO, db, &lds);
+    NoBody::Args none{0};
+    if (WG_FIRST) return launch_multi<WG, DG, ColsumBody, NoBody>(aw, nw, ad, nd, ac, nc, none, 0, lds, s);
+    return launch_multi<DG, WG, ColsumBody, NoBody>(ad, nd, aw, nw, ac, nc, none, 0, lds, s);
+}
+
+DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, int frames, const void* dy, const void* w, float* dw,
+                         float* db, void* dx, int splits, hipStream_t s) {
+    if (frames <= 0) return -1;
+    const int variant = splits >> 16;          // tile variant in the high half (tuning hook), split count in the low half
+    splits &= 0xffff;
+    if (layer == 1) {
+        const int rows = frames * Conv1Op::OH * Conv1Op::OW;
+        if (frame_off)
+            return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1OffOp>>(Conv1OffOp{x, frame_off, rows}, 32, Conv1Op::K,
+                                                                                              1.0f / 255.0f, dy, dw, db, splits, s);
+        return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1Op>>(Conv1Op{x, nullptr, rows}, 32, Conv1Op::K,
+                                                                                       1.0f / 255.0f, dy, dw, db, splits, s);
+    }
+#define CB2(bk, d, f) return conv_bwd_3<20, 20, 4, 2, 32, 64, 128, 32, 4, 1, Conv2Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, s)
+#define CB3(bk, d, f) return conv_bwd_3<9, 9, 3, 1, 64, 64, 128, 64, 2, 2, Conv3Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, s)
+    // variant (tuning hook): K-tile / ring depth of the weight-gradient body and the order of the bodies. The launch
+    // allocates max(LDS) and max(VGPR) of its bodies for EVERY workgroup, so a fat wgrad body halves the number of
+    // resident dgrad workgroups.
+    if (layer == 2) switch (variant) {
+        case 0: CB2(128, 2, false);
+        case 1: CB2(64, 4, false);
+        case 2: CB2(64, 2, false);
+        case 3: CB2(64, 4, true);
+        case 4: CB2(64, 2, true);
+        case 5: CB2(128, 2, true);
+    }
+    if (layer == 3) switch (variant) {
+        case 0: CB3(128, 2, false);
+        case 1: CB3(64, 4, false);
+        case 2: CB3(64, 2, false);
+        case 3: CB3(64, 4, true);
+        case 4: CB3(64, 2, true);
+        case 5: CB3(128, 2, true);
+    }
+#undef CB2
+#undef CB3
+    return -1;
 }

@@ -7,6 +7,7 @@
 // epsilon-greedy draw in the same wave — Q never takes a second kernel, and actor inference ends here with the
 // action already selected on device (per-env epsilon vector, Philox RNG; no host `random`).
 #include "common.h"
+#include "head_bwd_body.h"
 
 #define MAX_A 32
 #define HID 512
@@ -114,54 +115,12 @@ __global__ __launch_bounds__(256) void k_head_bwd_dh(const float* __restrict__ d
     d[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
-// Weight grads, accumulated with fp32 atomics into ZEROED buffers.
-// grid = (4, ceil(M/DW_ROWS)); block = 256: thread owns hidden column k = blockIdx.x*256 + tid of the 1024.
-#define DW_ROWS 16
+// Weight grads: see head_bwd_body.h. grid = (4, ceil(M/DW_ROWS)); block = 256.
 __global__ __launch_bounds__(256) void k_head_bwd_dw(const float* __restrict__ dq, const bf16_t* __restrict__ h, int M, int A,
                                                     float* __restrict__ gw_adv, float* __restrict__ gb_adv /* may be null */,
                                                     float* __restrict__ gw_val, float* __restrict__ gb_val) {
-    __shared__ float s_d[DW_ROWS][MAX_A + 1];    // [r][0..A-1] = dadv, [r][A] = dval
-    const int r0 = blockIdx.y * DW_ROWS;
-    const int nr = min(DW_ROWS, M - r0);
-    for (int i = threadIdx.x; i < DW_ROWS * (A + 1); i += 256) {
-        int r = i / (A + 1), j = i % (A + 1);
-        float v = 0.f;
-        if (r < nr) {
-            const float* q = dq + (long long)(r0 + r) * A;
-            float s = 0.f;
-            for (int t = 0; t < A; ++t) s += q[t];
-            v = (j < A) ? q[j] - s / (float)A : s;
-        }
-        s_d[r][j] = v;
-    }
-    __syncthreads();
-    const int k = blockIdx.x * 256 + threadIdx.x;     // 0..1023
-    const bool adv_half = k < HID;
-    float acc[MAX_A];
-#pragma unroll
-    for (int j = 0; j < MAX_A; ++j) acc[j] = 0.f;
-    float accv = 0.f;
-    for (int r = 0; r < nr; ++r) {
-        const float hv = bf2f(h[(long long)(r0 + r) * (2 * HID) + k]);
-        if (adv_half) {
-#pragma unroll
-            for (int j = 0; j < MAX_A; ++j) if (j < A) acc[j] += s_d[r][j] * hv;
-        } else {
-            accv += s_d[r][A] * hv;
-        }
-    }
-    if (adv_half) {
-#pragma unroll
-        for (int j = 0; j < MAX_A; ++j) if (j < A) atomicAdd(&gw_adv[(long long)j * HID + k], acc[j]);
-    } else {
-        atomicAdd(&gw_val[k - HID], accv);
-    }
-    if (blockIdx.x == 0 && threadIdx.x <= A) {
-        float s = 0.f;
-        for (int r = 0; r < nr; ++r) s += s_d[r][threadIdx.x];
-        if (threadIdx.x < A) { if (gb_adv) atomicAdd(&gb_adv[threadIdx.x], s); }
-        else atomicAdd(&gb_val[0], s);
-    }
+    __shared__ float s_d[DW_ROWS * (HEAD_MAX_A + 1)];
+    head_dw_block(dq, h, M, A, gw_adv, gb_adv, gw_val, gb_val, blockIdx.x, blockIdx.y, s_d);
 }
 
 DRL_API int drl_head_fwd(const void* h, int M, int A, const void* w_adv, const float* b_adv, const void* w_val, const float* b_val,

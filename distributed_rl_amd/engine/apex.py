@@ -95,6 +95,7 @@ class ApexEngine:
         self.n_scale = 1.0                               # N_global / (world * N_local): see refresh_shard_scalars
         import os as _os
         self.overlap_comm = _os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
+        self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
         # (online forward -> TD -> dgrad chain); see engine/streams.py
@@ -149,6 +150,12 @@ class ApexEngine:
         sp = self.wgrad_splits
         hb = (self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
               G.view("val2.w"), G.view("val2.b"))
+        if self.fused_bwd:
+            # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
+            H.head_bwd(*hb, parts=1)                               # dh
+            H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
+                     head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))
+            return
         with self._fork(1):                                        # head dW, db: off the critical path
             H.head_bwd(*hb, parts=2)
         H.head_bwd(*hb, parts=1)                                   # dh
@@ -163,6 +170,13 @@ class ApexEngine:
         G, Pb, on = self.G, self.Pb, self.on
         a2, a1 = on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
+        if self.fused_bwd:                                         # dX + dW + db of a layer = one launch
+            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), self.d2, B, splits=sp)
+            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), self.d1, B, splits=sp)
+            H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
+                       splits=4 * sp)
+            self._join()
+            return
         with self._fork(1):                                        # conv3 dW, db || conv3 dX
             H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
             H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)

@@ -18,6 +18,7 @@ class ForkJoin:
     def __init__(self, device, n_side: int = 2, enabled: bool = True):
         self.enabled = enabled and os.environ.get("DRL_OVERLAP", "1") != "0"
         self.side = [torch.cuda.Stream(device) for _ in range(n_side)] if self.enabled else []
+        self._open = set()           # side streams forked since the last join
 
     def fork(self, i: int):
         """Context manager: the body runs on side stream ``i`` after everything issued so far on the current stream."""
@@ -25,13 +26,16 @@ class ForkJoin:
             return contextlib.nullcontext()
         side = self.side[i % len(self.side)]
         side.wait_stream(torch.cuda.current_stream())
+        self._open.add(i % len(self.side))
         return torch.cuda.stream(side)
 
     def join(self) -> None:
-        """The current stream waits for every side stream."""
+        """The current stream waits for every side stream forked since the last join (a wait on an idle stream would
+        still be a cross-queue edge of the replayed graph)."""
         cur = torch.cuda.current_stream()
-        for side in self.side:
-            cur.wait_stream(side)
+        for i in sorted(self._open):
+            cur.wait_stream(self.side[i])
+        self._open.clear()
 
 
 def capture_graph(graph: "torch.cuda.CUDAGraph"):

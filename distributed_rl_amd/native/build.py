@@ -33,9 +33,9 @@ def _hash(path: str, extra: str = "") -> str:
     h = hashlib.sha1(extra.encode())
     with open(path, "rb") as fh:
         h.update(fh.read())
-    inc = os.path.join(os.path.dirname(path), "common.h")
-    if os.path.exists(inc):
-        with open(inc, "rb") as fh:
+    d = os.path.dirname(path)
+    for inc in sorted(f for f in os.listdir(d) if f.endswith(".h")):     # every header: they are few and small
+        with open(os.path.join(d, inc), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 

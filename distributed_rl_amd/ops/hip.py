@@ -270,6 +270,45 @@ def conv_dgrad(layer: int, dy: torch.Tensor, w: torch.Tensor, act_in: Optional[t
 CONV_DGRAD_IMPLICIT = True     # False = dCol GEMM + col2im gather (the two-pass form)
 
 
+# body configuration of the fused launches (see drl_fc_bwd / drl_conv_bwd), measured at B = 512 (scripts/kbench.py --only
+# fused): fc1 38.6 us with both ring-4 bodies -> 29.7 us with ring-2 bodies, dW issued first (fewer VGPRs: more
+# resident workgroups for BOTH bodies); conv2 40.5 -> 29.8 us with a 64-deep ring-2 wgrad body issued first (32 KB LDS
+# instead of 64 KB for every workgroup of the launch); conv3 25.2 -> 24.6 us.
+FC_BWD_VARIANT = 5
+CONV_BWD_VARIANT = {1: 0, 2: 4, 3: 2}
+
+
+def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], dw: torch.Tensor, db: torch.Tensor,
+             dx: Optional[torch.Tensor], frames: int, frame_off: Optional[torch.Tensor] = None, splits: int = 32,
+             variant: Optional[int] = None) -> None:
+    """Whole backward of a conv layer as ONE launch (k_multi in gemm.hip): implicit input gradient dx (layers 2/3, masked
+    by relu'(x)), split-K weight gradient accumulated into the ZEROED dw, bias gradient accumulated into the zeroed db.
+    x = the layer's forward input (layer 1: uint8 frames, optionally via frame_off byte offsets)."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
+    if layer != 1:
+        _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
+    variant = CONV_BWD_VARIANT[layer] if variant is None else variant
+    _ck(native.hip().drl_conv_bwd(layer, _p(x), _p(frame_off), frames, _p(dy), _p(w), _p(dw), _p(db), _p(dx),
+                                  splits | (variant << 16), _s()), "conv_bwd")
+
+
+def fc_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: torch.Tensor, dx: torch.Tensor,
+           M: int, N: int, K: int, head=None, variant: Optional[int] = None) -> None:
+    """Whole backward of y = relu-input FC layer as ONE launch: dx[M,K] = relu'(x) * (dy[M,N] @ w[N,K]), dw[N,K] = dy^T @ x
+    (overwritten), db[N] += colsum(dy). head = (dq, h, gw_adv, gb_adv, gw_val, gb_val) additionally runs the dueling
+    head's weight-gradient kernel inside the same launch (it only depends on dq and h)."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w")
+    _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db"); _chk(dx, torch.bfloat16, "dx")
+    if head is not None:
+        dq, h, gw_adv, gb_adv, gw_val, gb_val = head
+        _chk(dq, torch.float32, "dq"); _chk(h, torch.bfloat16, "h")
+        hargs = (_p(dq), _p(h), dq.shape[1], _p(gw_adv), _p(gb_adv), _p(gw_val), _p(gb_val))
+    else:
+        hargs = (None, None, 0, None, None, None, None)
+    _ck(native.hip().drl_fc_bwd(_p(dy), _p(x), _p(w), _p(dw), _p(db), _p(dx), M, N, K, *hargs,
+                                FC_BWD_VARIANT if variant is None else variant, _s()), "fc_bwd")
+
+
 def col2im(layer: int, dcol: torch.Tensor, act_in: torch.Tensor, dx: torch.Tensor, frames: int) -> None:
     _ck(native.hip().drl_col2im(layer, _p(dcol), _p(act_in), _p(dx), frames, _s()), "col2im")
 

@@ -125,6 +125,17 @@ def main():
     cases["colsum_d1"] = (lambda: H.colsum(d1v, db, B * 400, 32), 0, 2 * B * 400 * 32)
     dbh = torch.zeros(1024, device=DEV)
     cases["colsum_dh"] = (lambda: H.colsum(dh, dbh, B, 1024), 0, 2 * B * 1024)
+    # horizontally fused backward launches (dX + dW + db in one launch) and their body variants
+    dq = torch.randn(B, 4, device=DEV) * 0.01
+    gwa, gba, gwv, gbv = torch.zeros(4, 512, device=DEV), torch.zeros(4, device=DEV), torch.zeros(1, 512, device=DEV), torch.zeros(1, device=DEV)
+    hq = bf(B, 1024)
+    for v in range(6):
+        cases["fc1_bwd_fused_v%d" % v] = (lambda v=v: H.fc_bwd(dh, a3[:B], wfc, gfc, dbh, d3, B, 1024, 3136, head=(dq, hq, gwa, gba, gwv, gbv), variant=v), 4 * B * 1024 * 3136, 0)
+    for v in range(6):
+        cases["conv3_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(3, a2[:B], d3v, w3, g3, db, dx2, B, splits=32, variant=v), 2 * B * (49 + 81) * 64 * 576, 0)
+        cases["conv2_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(2, a1[:B], d2v, w2, g2, db, dx1, B, splits=32, variant=v), 2 * B * 81 * 64 * 512 + 2 * B * 400 * 32 * 256, 0)
+    db1 = torch.zeros(32, device=DEV)
+    cases["conv1_bwd_fused"] = (lambda: H.conv_bwd(1, x, d1v, None, g1, db1, None, B, frame_off=foff, splits=128), 2 * B * 400 * 32 * 256, 0)
     # R2D2-sized GEMMs
     N = 7680
     feat = bf(N, 3136)

@@ -483,6 +483,81 @@ def test_conv_dgrad(hip, layer, frames):
     torch.testing.assert_close(dx3.float().cpu(), ref_nomask, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("frames,splits,variant", [(3, 1, None), (33, 8, 0), (512, 32, None), (40, 4, 1), (40, 4, 3), (40, 4, 5)])
+def test_conv_bwd_fused(hip, layer, frames, splits, variant):
+    """dX + dW + db of a conv layer as ONE launch (k_multi) against autograd of the fp32 convolution."""
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 17 + frames)
+    oh = (hw - ks) // s + 1
+    g = torch.Generator().manual_seed(13)
+    dy = bf(torch.randn(frames, oh, oh, cout, generator=g) * 0.1)
+    xin = xf.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wf = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    bf_ = bias.clone().requires_grad_(True)
+    F.conv2d(xin, wf, bf_, stride=s).backward(dy.float().permute(0, 3, 1, 2))
+    dw = torch.zeros(cout, ks, ks, cin, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    dx = torch.full((frames, hw, hw, cin), 7.0, dtype=torch.bfloat16, device=DEV) if layer != 1 else None
+    H.conv_bwd(layer, x.to(DEV), dy.to(DEV), w.to(DEV) if layer != 1 else None, dw, db, dx, frames, splits=splits,
+               variant=variant if layer != 1 else None)
+    ref = wf.grad.permute(0, 2, 3, 1)
+    torch.testing.assert_close(dw.cpu(), ref, rtol=5e-3, atol=5e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(db.cpu(), bf_.grad, rtol=1e-3, atol=1e-3 * max(1.0, (frames * oh * oh) ** 0.5))
+    if layer != 1:
+        rdx = xin.grad.permute(0, 2, 3, 1) * (xf > 0)
+        torch.testing.assert_close(dx.float().cpu(), rdx, rtol=3e-2, atol=3e-2 * float(rdx.abs().max()))
+
+
+def test_conv1_bwd_fused_frame_offsets(hip):
+    H = hip
+    store = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    pick = torch.tensor([7, 3, 19, 7, 0])
+    g = torch.Generator().manual_seed(14)
+    dy = bf(torch.randn(5, 20, 20, 32, generator=g) * 0.1).to(DEV)
+    dw, db = torch.zeros(32, 8, 8, 4, device=DEV), torch.zeros(32, device=DEV)
+    H.conv_bwd(1, store.to(DEV), dy, None, dw, db, None, 5, frame_off=(pick * 28224).to(DEV), splits=4)
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    H.conv_wgrad(1, store[pick].contiguous().to(DEV), dy, dw2, 5, splits=1)
+    H.colsum(dy, db2, 5 * 400, 32)
+    torch.testing.assert_close(dw, dw2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,A,with_head,variant", [(512, 4, True, None), (64, 18, True, 0), (100, 6, False, 2), (70, 4, True, 5)])
+def test_fc_bwd_fused(hip, M, A, with_head, variant):
+    """fc1 backward (dX masked, dW, db) + dueling-head weight gradients in one launch vs fp32 matmuls / the stand-alone
+    head kernel."""
+    H = hip
+    N, K = 1024, 3136
+    g = torch.Generator().manual_seed(M + A)
+    dy = bf(torch.randn(M, N, generator=g) * 0.1)
+    x = bf(torch.relu(torch.randn(M, K, generator=g)))
+    w = bf(torch.randn(N, K, generator=g) * 0.02)
+    dw = torch.full((N, K), 3.0, device=DEV)                   # overwritten
+    db = torch.zeros(N, device=DEV)
+    dx = torch.full((M, K), 7.0, dtype=torch.bfloat16, device=DEV)
+    head = None
+    if with_head:
+        dq = (torch.randn(M, A, generator=g) * 0.1).to(DEV)
+        hq = bf(torch.relu(torch.randn(M, 1024, generator=g))).to(DEV)
+        gw_adv, gb_adv = torch.zeros(A, 512, device=DEV), torch.zeros(A, device=DEV)
+        gw_val, gb_val = torch.zeros(1, 512, device=DEV), torch.zeros(1, device=DEV)
+        head = (dq, hq, gw_adv, gb_adv, gw_val, gb_val)
+    H.fc_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), dw, db, dx, M, N, K, head=head, variant=variant)
+    torch.testing.assert_close(dw.cpu(), dy.float().t() @ x.float(), rtol=3e-3, atol=3e-2)
+    torch.testing.assert_close(db.cpu(), dy.float().sum(0), rtol=1e-3, atol=1e-3 * M ** 0.5)
+    rdx = (dy.float() @ w.float()) * (x.float() > 0)
+    torch.testing.assert_close(dx.float().cpu(), rdx, rtol=2e-2, atol=2e-2 * float(rdx.abs().max()))
+    if with_head:
+        r = [torch.zeros_like(t) for t in (gw_adv, gb_adv, gw_val, gb_val)]
+        wz = torch.zeros(A, 512, dtype=torch.bfloat16, device=DEV)
+        dh = torch.zeros(M, 1024, dtype=torch.bfloat16, device=DEV)
+        H.head_bwd(dq, hq, wz, wz[:1], dh, *r, parts=2)
+        for got, want in zip((gw_adv, gb_adv, gw_val, gb_val), r):
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
 # ---- LSTM recurrence -----------------------------------------------------------------------------------
 def _lstm_case(T, M, Hd, seed):
     from distributed_rl_amd.models.packing import _gate_interleave
