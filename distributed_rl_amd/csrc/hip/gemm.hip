@@ -25,6 +25,7 @@
 #include "common.h"
 #include "colsum_body.h"
 #include "head_bwd_body.h"
+#include "sumtree_body.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -752,6 +753,47 @@ struct HeadDwBody {
     }
 };
 
+// One stage of the PER priority write-back (sumtree.hip) riding along with a backward launch: the write-back depends
+// only on the TD kernel's output, so its two stages run inside two CONSECUTIVE fused launches of the conv backward.
+struct TreeExtra {        // host-side description (ctypes mirror: ops/hip.py TreeExtra)
+    int kind;             // 0 none | 1 leaves + level 1 | 2 levels >= 2 (+ st_end: step += 1) | 3 step += 1 only
+    int n_levels;
+    float* base;
+    long long off[MAX_LEVELS];
+    long long cap;
+    const int* idx;
+    const float* val;
+    int n, pad;
+    const int* gen;
+    const int* gen_expected;
+    void* st_end;
+};
+
+struct TreeBody {
+    struct Args { TreeDesc tr; const int* idx; const float* val; int n, kind, n2_blocks; const int* gen; const int* gen_expected; StepState* st_end; };
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        if (g.kind == 1) tree_update_l01_block(g.tr, g.idx, g.val, g.n, g.gen, g.gen_expected, block);
+        else if (g.kind == 2) tree_rebuild_upper_block(g.tr, g.n2_blocks, g.st_end, block, reinterpret_cast<float*>(smem));
+        else if (block == 0 && threadIdx.x == 0 && g.st_end) g.st_end->step += 1;
+    }
+    static int plan(Args& g, const TreeExtra* e, size_t* lds) {
+        g.kind = 0;
+        if (!e || e->kind == 0) return 0;
+        if (e->n_levels < 1 || e->n_levels > MAX_LEVELS) return -1;
+        g.tr = make_desc(e->base, e->n_levels, e->off, e->cap);
+        g.idx = e->idx; g.val = e->val; g.n = e->n; g.kind = e->kind; g.gen = e->gen; g.gen_expected = e->gen_expected;
+        g.st_end = (StepState*)e->st_end; g.n2_blocks = 0;
+        if (*lds < 17 * 4) *lds = 17 * 4;
+        if (e->kind == 1) return e->n > 0 ? (e->n + 3) / 4 : -1;
+        if (e->kind == 2) {
+            const long long blocks = tree_upper_blocks(g.tr, &g.n2_blocks);
+            if (blocks > 0) return (int)blocks;
+            g.kind = 3;
+        }
+        return g.st_end ? 1 : 0;
+    }
+};
+
 struct NoBody {
     struct Args { int unused; };
     static __device__ __forceinline__ void run(const Args&, int, uint8_t*) {}
@@ -827,18 +869,21 @@ DRL_API int drl_fc_bwd(const void* dy, const void* x, const void* w, float* dw, 
 // x = the layer's forward input (layer 1: uint8 frames, optionally through frame_off; layers 2/3: NHWC bf16 activation,
 // which is also the ReLU mask of dX). dY = d(pre-activation) of this layer's output, NHWC bf16.
 template <class WG, class BOp>
-static int conv_bwd_12(const BOp& B, int cout, int kdim, float scale, const void* dy, float* dw, float* db, int splits, hipStream_t s) {
+static int conv_bwd_12(const BOp& B, int cout, int kdim, float scale, const void* dy, float* dw, float* db, int splits,
+                       const TreeExtra* extra, hipStream_t s) {
     size_t lds = 0;
-    typename WG::Args aw; ColsumBody::Args ac;
+    typename WG::Args aw; ColsumBody::Args ac; TreeBody::Args at;
+    const int nt = TreeBody::plan(at, extra, &lds);
     const int nw = WG::plan(aw, DenseOp{(const bf16_t*)dy, cout, B.rows}, B, cout, kdim, B.rows, splits,
                             make_epi(dw, kdim, nullptr, nullptr, 0, scale, EPI_OUT_F32 | EPI_ATOMIC), 0, &lds);
     const int nc = ColsumBody::plan(ac, dy, B.rows, cout, db, &lds);
     NoBody::Args none{0};
-    return launch_multi<WG, ColsumBody, NoBody, NoBody>(aw, nw, ac, nc, none, 0, none, 0, lds, s);
+    return launch_multi<WG, ColsumBody, TreeBody, NoBody>(aw, nw, ac, nc, at, nt, none, 0, lds, s);
 }
 
 template <int H, int W, int KS, int S, int CI, int CO, int BM, int BN, int WM, int WN, class COp, int WBK, int WD, bool WG_FIRST>
-static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, float* dw, float* db, void* dx, int splits, hipStream_t s) {
+static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, float* dw, float* db, void* dx, int splits,
+                      const TreeExtra* extra, hipStream_t s) {
     typedef DgradOp<H, W, KS, S, CO> AOp;
     typedef WdgradOp<KS, S, CI, CO> BOp;
     typedef GemmBody<BM, BN, 64, WM, WN, false, true, 2, AOp, BOp> DG;
@@ -846,7 +891,8 @@ static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, 
     const int M = frames * AOp::HC * AOp::WC;
     if ((long long)frames * AOp::OH * AOp::OW * CO >= (1LL << 40)) return -8;
     size_t lds = 0;
-    typename DG::Args ad; typename WG::Args aw; ColsumBody::Args ac;
+    typename DG::Args ad; typename WG::Args aw; ColsumBody::Args ac; TreeBody::Args at;
+    const int nt = TreeBody::plan(at, extra, &lds);
     Epilogue ep = make_epi(dx, CI, nullptr, x, CI, 1.0f, EPI_MASK | EPI_REMAP);
     ep.rm_hc = AOp::HC; ep.rm_wc = AOp::WC; ep.rm_s = S; ep.rm_h = H; ep.rm_w = W;
     const int nd = DG::plan(ad, AOp{(const bf16_t*)dy, M, 0, 0}, BOp{(const bf16_t*)w, 0, 0}, M, CI, AOp::K, 1, ep, S * S, &lds);
@@ -854,13 +900,14 @@ static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, 
     const int nw = WG::plan(aw, DenseOp{(const bf16_t*)dy, CO, B.rows}, B, CO, COp::K, B.rows, splits,
                             make_epi(dw, COp::K, nullptr, nullptr, 0, 1.0f, EPI_OUT_F32 | EPI_ATOMIC), 0, &lds);
     const int nc = ColsumBody::plan(ac, dy, B.rows, CO, db, &lds);
-    NoBody::Args none{0};
-    if (WG_FIRST) return launch_multi<WG, DG, ColsumBody, NoBody>(aw, nw, ad, nd, ac, nc, none, 0, lds, s);
-    return launch_multi<DG, WG, ColsumBody, NoBody>(ad, nd, aw, nw, ac, nc, none, 0, lds, s);
+    if (WG_FIRST) return launch_multi<WG, DG, ColsumBody, TreeBody>(aw, nw, ad, nd, ac, nc, at, nt, lds, s);
+    return launch_multi<DG, WG, ColsumBody, TreeBody>(ad, nd, aw, nw, ac, nc, at, nt, lds, s);
 }
 
+// extra (optional, host pointer to a TreeExtra): a stage of the PER priority write-back to run inside the same launch.
 DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, int frames, const void* dy, const void* w, float* dw,
-                         float* db, void* dx, int splits, hipStream_t s) {
+                         float* db, void* dx, int splits, const void* extra_, hipStream_t s) {
+    const TreeExtra* extra = (const TreeExtra*)extra_;
     if (frames <= 0) return -1;
     const int variant = splits >> 16;          // tile variant in the high half (tuning hook), split count in the low half
     splits &= 0xffff;
@@ -868,12 +915,12 @@ DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, i
         const int rows = frames * Conv1Op::OH * Conv1Op::OW;
         if (frame_off)
             return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1OffOp>>(Conv1OffOp{x, frame_off, rows}, 32, Conv1Op::K,
-                                                                                              1.0f / 255.0f, dy, dw, db, splits, s);
+                                                                                              1.0f / 255.0f, dy, dw, db, splits, extra, s);
         return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1Op>>(Conv1Op{x, nullptr, rows}, 32, Conv1Op::K,
-                                                                                       1.0f / 255.0f, dy, dw, db, splits, s);
+                                                                                       1.0f / 255.0f, dy, dw, db, splits, extra, s);
     }
-#define CB2(bk, d, f) return conv_bwd_3<20, 20, 4, 2, 32, 64, 128, 32, 4, 1, Conv2Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, s)
-#define CB3(bk, d, f) return conv_bwd_3<9, 9, 3, 1, 64, 64, 128, 64, 2, 2, Conv3Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, s)
+#define CB2(bk, d, f) return conv_bwd_3<20, 20, 4, 2, 32, 64, 128, 32, 4, 1, Conv2Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)
+#define CB3(bk, d, f) return conv_bwd_3<9, 9, 3, 1, 64, 64, 128, 64, 2, 2, Conv3Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)
     // variant (tuning hook): K-tile / ring depth of the weight-gradient body and the order of the bodies. The launch
     // allocates max(LDS) and max(VGPR) of its bodies for EVERY workgroup, so a fat wgrad body halves the number of
     // resident dgrad workgroups.

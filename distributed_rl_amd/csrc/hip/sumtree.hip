@@ -15,15 +15,7 @@
 //     bumps a per-slot generation; priority write-backs carry the generation they sampled and are dropped
 //     if the slot was overwritten meanwhile.
 #include "common.h"
-
-#define MAX_LEVELS 6
-
-struct TreeDesc {
-    float* base;
-    int n_levels;               // level 0 = leaves ... level n_levels-1 = top (<= 64 nodes)
-    long long off[MAX_LEVELS];  // element offset of each level inside base
-    long long cap;              // number of leaf slots (ring capacity)
-};
+#include "sumtree_body.h"
 
 __global__ void k_step_begin(StepState* st, const long long* n_items) {
     if (threadIdx.x == 0) {
@@ -121,36 +113,7 @@ __global__ __launch_bounds__(256) void k_fix_level(TreeDesc tr, int level, const
 // write identical values.
 __global__ __launch_bounds__(256) void k_update_l01(TreeDesc tr, const int* __restrict__ idx, const float* __restrict__ val,
                                                    int n, const int* __restrict__ gen, const int* __restrict__ gen_expected) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int s = idx[i];
-    if (s < 0 || s >= tr.cap) return;
-    if (gen && gen_expected && gen[s] != gen_expected[i]) return;
-    const long long node = (long long)s >> 6;
-    float v = tr.base[tr.off[0] + node * 64 + lane];
-    for (int c = 0; c < n; c += 64) {
-        const int j = c + lane;
-        int sj = -1;
-        if (j < n) {
-            sj = idx[j];
-            if (sj < 0 || sj >= tr.cap || ((long long)sj >> 6) != node) sj = -1;
-            else if (gen && gen_expected && gen[sj] != gen_expected[j]) sj = -1;
-        }
-        unsigned long long m = __ballot(sj >= 0);
-        while (m) {
-            const int bpos = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int t = __shfl(sj, bpos, WAVE);
-            const float x = val[c + bpos];
-            if (lane == (t & 63)) v = x;
-        }
-    }
-    tr.base[tr.off[0] + node * 64 + lane] = v;
-    if (tr.n_levels > 1) {
-        const float sum = wave_sum(v);
-        if (lane == 0) tr.base[tr.off[1] + node] = sum;
-    }
+    tree_update_l01_block(tr, idx, val, n, gen, gen_expected, blockIdx.x);
 }
 
 // K2: every node of every level >= 2 is rebuilt directly FROM LEVEL 1 (a level-l node covers 64^(l-1) level-1 values),
@@ -158,34 +121,7 @@ __global__ __launch_bounds__(256) void k_update_l01(TreeDesc tr, const int* __re
 // one wave per node; levels >= 3: one block per node. Block 0 optionally ends the step (step += 1).
 __global__ __launch_bounds__(256) void k_rebuild_upper(TreeDesc tr, int n2_blocks, StepState* st_end) {
     __shared__ float red[17];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && st_end) st_end->step += 1;
-    if (tr.n_levels < 3) return;
-    const long long n1 = tr.off[2] - tr.off[1];                    // padded level-1 size (zeros past the live nodes)
-    const float* l1 = tr.base + tr.off[1];
-    if ((int)blockIdx.x < n2_blocks) {
-        const long long node = (long long)blockIdx.x * 4 + wave;
-        const long long n2 = (n1 + 63) / 64;
-        if (node >= n2) return;
-        const long long k = node * 64 + lane;
-        const float v = wave_sum(k < n1 ? l1[k] : 0.f);
-        if (lane == 0) tr.base[tr.off[2] + node] = v;
-        return;
-    }
-    // levels >= 3: find (level, node) of this block
-    long long rest = (long long)blockIdx.x - n2_blocks, span = 64LL * 64;
-    int lvl = 3;
-    for (; lvl < tr.n_levels; ++lvl, span *= 64) {
-        const long long nl = (n1 + span - 1) / span;
-        if (rest < nl) break;
-        rest -= nl;
-    }
-    if (lvl >= tr.n_levels) return;
-    const long long k0 = rest * span, k1 = min(n1, k0 + span);
-    float acc = 0.f;
-    for (long long k = k0 + threadIdx.x; k < k1; k += 256) acc += l1[k];
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) tr.base[tr.off[lvl] + rest] = acc;
+    tree_rebuild_upper_block(tr, n2_blocks, st_end, blockIdx.x, red);
 }
 
 // Ring ingest: slots [start, start+n) mod cap get new priorities and a new generation.
@@ -214,13 +150,6 @@ __global__ void k_gather_scalar(const T* __restrict__ src, const int* __restrict
     dst[i] = src[(long long)idx[i / inner] * inner + (i % inner)];
 }
 
-static TreeDesc make_desc(float* base, int n_levels, const long long* off, long long cap) {
-    TreeDesc d;
-    d.base = base; d.n_levels = n_levels; d.cap = cap;
-    for (int i = 0; i < MAX_LEVELS; ++i) d.off[i] = i < n_levels ? off[i] : 0;
-    return d;
-}
-
 DRL_API int drl_step_begin(void* st, const long long* n_items, hipStream_t s) {
     k_step_begin<<<1, 64, 0, s>>>((StepState*)st, n_items);
     return (int)hipGetLastError();
@@ -242,14 +171,12 @@ DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, 
 }
 
 static void rebuild_upper(const TreeDesc& d, void* st_end, hipStream_t s) {
-    if (d.n_levels < 3) {
+    int n2_blocks;
+    const long long blocks = tree_upper_blocks(d, &n2_blocks);
+    if (blocks == 0) {
         if (st_end) k_step_end<<<1, 64, 0, s>>>((StepState*)st_end);
         return;
     }
-    const long long n1 = d.off[2] - d.off[1];
-    const int n2_blocks = (int)(((n1 + 63) / 64 + 3) / 4);
-    long long blocks = n2_blocks, span = 64LL * 64;
-    for (int l = 3; l < d.n_levels; ++l, span *= 64) blocks += (n1 + span - 1) / span;
     k_rebuild_upper<<<(unsigned)blocks, 256, 0, s>>>(d, n2_blocks, (StepState*)st_end);
 }
 

@@ -171,8 +171,12 @@ class ApexEngine:
         a2, a1 = on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
         if self.fused_bwd:                                         # dX + dW + db of a layer = one launch
-            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), self.d2, B, splits=sp)
-            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), self.d1, B, splits=sp)
+            # the PER priority write-back (needs only the TD kernel's output) rides along as an extra body: leaves +
+            # level 1 inside the conv3 launch, upper levels + step_end inside the conv2 launch
+            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), self.d2, B, splits=sp,
+                       extra=r.update_stage(1, self.new_prio))
+            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), self.d1, B, splits=sp,
+                       extra=r.update_stage(2, self.new_prio, end_state=self.st))
             H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
                        splits=4 * sp)
             self._join()
@@ -204,7 +208,8 @@ class ApexEngine:
         H.grad_sumsq(self.G.flat, self.partial)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
                        1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True)
-        self.replay.update(self.new_prio, end_state=self.st)        # step_end fused into the tree rebuild
+        if not self.fused_bwd:                                      # fused: done inside the conv backward launches
+            self.replay.update(self.new_prio, end_state=self.st)    # step_end fused into the tree rebuild
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
@@ -253,6 +258,8 @@ class ApexEngine:
         torch.cuda.synchronize()
         import os
         collective = self.dist is not None and self.dist.enabled
+        if collective and self.dist.graph_collectives:
+            self.dist.quiesce()        # the watchdog must have retired the warm-up steps' eager collectives (see Dist.quiesce)
         if not collective or self.dist.graph_collectives:
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduces (overlapped schedule included) are
             # captured into it as well: no host work at all between sampling and the priority write-back

@@ -269,6 +269,8 @@ class R2D2Engine:
         torch.cuda.synchronize()
         import os
         collective = self.dist is not None and self.dist.enabled
+        if collective and self.dist.graph_collectives:
+            self.dist.quiesce()        # the watchdog must have retired the warm-up steps' eager collectives (see Dist.quiesce)
         if not collective or self.dist.graph_collectives:
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()

@@ -34,7 +34,7 @@ SIGS = {
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
-    "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P],
+    "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P],
     "drl_fc_bwd": [P, P, P, P, P, P, I, I, I, P, P, I, P, P, P, P, I, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip

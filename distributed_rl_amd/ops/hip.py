@@ -278,9 +278,34 @@ FC_BWD_VARIANT = 5
 CONV_BWD_VARIANT = {1: 0, 2: 4, 3: 2}
 
 
+class TreeExtra(ctypes.Structure):
+    """ctypes mirror of ``TreeExtra`` (csrc/hip/gemm.hip): one stage of the PER priority write-back that rides along with
+    a fused conv-backward launch. kind 1 = leaves + level 1, 2 = levels >= 2 (+ step_end), 3 = step_end only."""
+    _fields_ = [("kind", ctypes.c_int), ("n_levels", ctypes.c_int), ("base", ctypes.c_void_p),
+                ("off", ctypes.c_longlong * 6), ("cap", ctypes.c_longlong), ("idx", ctypes.c_void_p),
+                ("val", ctypes.c_void_p), ("n", ctypes.c_int), ("pad", ctypes.c_int), ("gen", ctypes.c_void_p),
+                ("gen_expected", ctypes.c_void_p), ("st_end", ctypes.c_void_p)]
+
+
+def tree_extra(kind: int, tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
+               gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
+               end_state: Optional[torch.Tensor] = None) -> TreeExtra:
+    _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
+    assert idx.numel() == val.numel()
+    e = TreeExtra()
+    e.kind, e.n_levels, e.base, e.cap = kind, lay.n_levels, tree.data_ptr(), lay.capacity
+    for i in range(6):
+        e.off[i] = int(lay.offsets[i]) if i < lay.n_levels else 0
+    e.idx, e.val, e.n = idx.data_ptr(), val.data_ptr(), idx.numel()
+    e.gen = gen.data_ptr() if gen is not None else None
+    e.gen_expected = gen_expected.data_ptr() if gen_expected is not None else None
+    e.st_end = end_state.data_ptr() if end_state is not None else None
+    return e
+
+
 def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], dw: torch.Tensor, db: torch.Tensor,
              dx: Optional[torch.Tensor], frames: int, frame_off: Optional[torch.Tensor] = None, splits: int = 32,
-             variant: Optional[int] = None) -> None:
+             variant: Optional[int] = None, extra: Optional["TreeExtra"] = None) -> None:
     """Whole backward of a conv layer as ONE launch (k_multi in gemm.hip): implicit input gradient dx (layers 2/3, masked
     by relu'(x)), split-K weight gradient accumulated into the ZEROED dw, bias gradient accumulated into the zeroed db.
     x = the layer's forward input (layer 1: uint8 frames, optionally via frame_off byte offsets)."""
@@ -289,7 +314,8 @@ def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Te
         _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
     variant = CONV_BWD_VARIANT[layer] if variant is None else variant
     _ck(native.hip().drl_conv_bwd(layer, _p(x), _p(frame_off), frames, _p(dy), _p(w), _p(dw), _p(db), _p(dx),
-                                  splits | (variant << 16), _s()), "conv_bwd")
+                                  splits | (variant << 16), ctypes.byref(extra) if extra is not None else None, _s()),
+        "conv_bwd")
 
 
 def fc_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: torch.Tensor, dx: torch.Tensor,

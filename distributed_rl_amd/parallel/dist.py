@@ -89,6 +89,18 @@ class Dist:
             self._graph_ok = self._trial_graph_collective()
         return self._graph_ok
 
+    def quiesce(self) -> None:
+        """Call before capturing a hipGraph that CONTAINS collectives. The process group's watchdog thread polls the end
+        events of eager collectives every 100 ms; HIP refuses ``hipEventQuery`` on an event whose stream is capturing
+        (hipErrorCapturedEvent), which the watchdog turns into a process abort. A captured collective pulls the group's
+        internal RCCL stream into the capture, so every eager collective issued before must have been RETIRED by the
+        watchdog first: finish the device work, then leave the watchdog a few polling periods."""
+        if not self.enabled or self.backend != "nccl":
+            return
+        import time
+        torch.cuda.synchronize(self.device)
+        time.sleep(float(os.environ.get("DRL_QUIESCE_S", "0.35")))
+
     def _trial_graph_collective(self) -> bool:
         if not self.enabled or self.device.type != "cuda" or self.backend != "nccl":
             return False
@@ -96,7 +108,7 @@ class Dist:
         try:
             x = torch.ones(4096, device=self.device)
             td.all_reduce(x)                                   # communicator warm-up outside capture
-            torch.cuda.synchronize(self.device)
+            self.quiesce()
             buf = torch.ones(4096, device=self.device)
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream())

@@ -124,6 +124,12 @@ class DevicePER:
         ``end_state`` fuses step_end into the tree rebuild launch."""
         H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
 
+    def update_stage(self, kind: int, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None):
+        """The same write-back as ``update`` split into its two stages (kind 1 = leaves + level 1, kind 2 = upper levels +
+        optional step_end) as ``TreeExtra`` records: the learner engine hands them to two consecutive fused backward
+        launches (ops.hip.conv_bwd) instead of launching them at the tail of the step."""
+        return H.tree_extra(kind, self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
+
     # host-API parity with PrioritizedMemory (tests / tools; not on the hot path)
     def update_priorities(self, indices, priorities) -> None:
         idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device)

@@ -9,6 +9,10 @@ The collective is blocking by nature and actors are asynchronous by design, so e
 that sits in ``broadcast`` waiting for the next publication (header = [version, numel]; version < 0 = shut down) and
 swaps the payload in under a lock; ``pull(have_version)`` never blocks. The learner publishes every K steps, exactly
 like the reference's ``SET params`` (ape_x/learner.py:83), but without touching the host.
+
+Give it its OWN process group (``group=torch.distributed.new_group(...)``) when the learner captures its gradient
+all-reduce into the step graph: eager collectives of a group whose RCCL stream is being captured make the group's
+watchdog abort the process (``Dist.quiesce`` in parallel/dist.py explains the mechanism).
 """
 from __future__ import annotations
 

@@ -509,6 +509,43 @@ def test_conv_bwd_fused(hip, layer, frames, splits, variant):
         torch.testing.assert_close(dx.float().cpu(), rdx, rtol=3e-2, atol=3e-2 * float(rdx.abs().max()))
 
 
+@pytest.mark.parametrize("cap", [50, 4000, 2_000_000])
+def test_conv_bwd_fused_tree_stages(hip, cap):
+    """The PER priority write-back as extra bodies of two consecutive fused conv-backward launches must leave the tree
+    exactly as the stand-alone two-launch update does (and the step counter advanced)."""
+    H = hip
+    lay = H.TreeLayout(cap)
+    g = torch.Generator().manual_seed(cap + 3)
+    prio = (torch.rand(cap, generator=g) + 0.01).to(DEV)
+    trees = []
+    B = 96
+    base = torch.randint(0, cap, (B,), generator=g)
+    base[:32] = (base[0] // 64 * 64 + torch.randint(0, 64, (32,), generator=g)).clamp(max=cap - 1)
+    base[40:44] = base[40]
+    ui, uv = base.int().to(DEV), (torch.rand(B, generator=g) + 0.5).to(DEV)
+    x3, _, w3, _, _ = _conv_setup(3, 4, 1)
+    x2, _, w2, _, _ = _conv_setup(2, 4, 2)
+    dy3 = bf(torch.randn(4, 7, 7, 64, generator=g) * 0.1).to(DEV)
+    dy2 = bf(torch.randn(4, 9, 9, 64, generator=g) * 0.1).to(DEV)
+    for fused in (False, True):
+        tree = torch.zeros(lay.total, device=DEV)
+        scratch = torch.zeros(cap, dtype=torch.int32, device=DEV)
+        H.sumtree_ingest(tree, lay, 0, prio, None, scratch)
+        st = H.new_step_state(DEV, 0.4, 100)
+        if fused:
+            dw3, dw2, db = torch.zeros(64, 3, 3, 64, device=DEV), torch.zeros(64, 4, 4, 32, device=DEV), torch.zeros(64, device=DEV)
+            dx3 = torch.zeros(4, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
+            dx2 = torch.zeros(4, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+            H.conv_bwd(3, x3.to(DEV), dy3, w3.to(DEV), dw3, db, dx3, 4, splits=2, extra=H.tree_extra(1, tree, lay, ui, uv))
+            H.conv_bwd(2, x2.to(DEV), dy2, w2.to(DEV), dw2, db, dx2, 4, splits=2, extra=H.tree_extra(2, tree, lay, ui, uv, end_state=st))
+            assert float(dw3.abs().sum()) > 0 and float(dx2.float().abs().sum()) > 0
+        else:
+            H.sumtree_update(tree, lay, ui, uv, end_state=st)
+        assert H.read_step_state(st)["step"] == 1
+        trees.append(tree.cpu())
+    assert torch.equal(trees[0], trees[1])
+
+
 def test_conv1_bwd_fused_frame_offsets(hip):
     H = hip
     store = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
