@@ -59,8 +59,12 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
     H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, N)
     H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
-    H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), buf.xg.view(N, 4 * Hd), N, 4 * Hd, 3136, bias=bsum,
-           flags=H.EPI_OUT_F32, big=N >= 1024)
+    xg = buf.xg.view(N, 4 * Hd)
+    if H.use_lib_gemm(N, 4 * Hd, 3136):        # big plain product: hipBLASLt (see ops.hip.lib_gemm), bias as a second pass
+        H.lib_gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), xg)
+        xg.add_(bsum)
+    else:
+        H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), xg, N, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=N >= 1024)
 
 
 def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers,
@@ -138,6 +142,7 @@ class R2D2Engine:
         self.wgrad_splits = wgrad_splits
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
+        self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
@@ -211,7 +216,10 @@ class R2D2Engine:
             H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
             G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
-        H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
+        if H.use_lib_gemm(4 * Hd, 3136, NB):
+            H.lib_gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"))
+        else:
+            H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
         fj.join()
 
     def _torso_backward(self, k0: int, k1: int) -> None:
@@ -224,7 +232,17 @@ class R2D2Engine:
         a3, a2, a1 = on.act3[r0 + lo:r0 + hi], on.act2[r0 + lo:r0 + hi], on.act1[r0 + lo:r0 + hi]
         d3, d2, d1 = self.d3[lo * 49:hi * 49], self.d2[lo * 81:hi * 81], self.d1[lo * 400:hi * 400]
         sp = max(8, self.wgrad_splits * n // NB)
-        H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
+        if H.use_lib_gemm(n, 3136, 4 * Hd):
+            H.lib_gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136))
+            H.relu_mask(d3, a3, d3)                                 # the mask the fused epilogue would have applied
+        else:
+            H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
+        if self.fused_bwd:                                          # dX + dW + db of a conv layer = one launch (k_multi)
+            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), d2, n, splits=sp)
+            H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), d1, n, splits=sp)
+            H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
+                       frame_off=r.frame_off[r0 + lo:r0 + hi], splits=2 * sp)
+            return
         H.conv_wgrad(3, a2, d3, G.view("conv3.w"), n, splits=sp)
         H.colsum(d3, G.view("conv3.b"), n * 49, 64)
         self._dgrad(3, d3, Pb.view("conv3.w"), self.dcol3, a2, d2, n)

@@ -6,6 +6,7 @@ fallback here: if ``libdrl_hip.so`` is missing these raise (oracle implementatio
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -342,6 +343,31 @@ def col2im(layer: int, dcol: torch.Tensor, act_in: torch.Tensor, dx: torch.Tenso
 def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
     _chk(dy, torch.bfloat16, "dy"); _chk(db, torch.float32, "db")
     _ck(native.hip().drl_colsum(_p(dy), M, N, _p(db), _s()), "colsum")
+
+
+# ---- library GEMM for the big PLAIN products ---------------------------------------------------------------------------
+# The hand-written tiled kernel (gemm.hip) is built for the small, latency-bound GEMMs of the Ape-X step and for fused
+# epilogues / implicit operands. On the few LARGE plain products of the R2D2 step (no epilogue, both operands dense) the
+# vendor library is 2-3x faster (measured, scripts/debug/mm_bench.py: 7680x2048x3136 NT 93 us vs 232 us, 2048x3136x5120
+# TN 102 vs 195 us, 5120x3136x2048 NN 95 vs 177 us), so those - and only those - go to hipBLASLt through torch.mm with fp32
+# accumulation and (where the consumer wants it) fp32 output. DRL_LIB_GEMM=0 keeps everything on gemm.hip.
+LIB_GEMM = os.environ.get("DRL_LIB_GEMM", "1") != "0"
+LIB_GEMM_MIN_FLOP = 2.0e10
+
+
+def use_lib_gemm(M: int, N: int, K: int) -> bool:
+    return LIB_GEMM and 2.0 * M * N * K >= LIB_GEMM_MIN_FLOP
+
+
+def lib_gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> None:
+    """c = a·bᵀ (NT), a·b (NN) or aᵀ·b (TN) for 2-D bf16 a, b; c bf16 or fp32 (fp32 accumulation either way)."""
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    lhs = a.t() if mode == TN else a
+    rhs = b.t() if mode == NT else b
+    if c.dtype == torch.float32:
+        torch.mm(lhs, rhs, out_dtype=torch.float32, out=c)
+    else:
+        torch.mm(lhs, rhs, out=c)
 
 
 def relu_mask(a: torch.Tensor, mask: torch.Tensor, out: torch.Tensor) -> None:

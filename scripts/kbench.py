@@ -143,6 +143,20 @@ def main():
     xg = torch.zeros(N, 2048, device=DEV)
     for v in (1, 4):
         cases["lstm_igemm_v%d" % v] = (lambda v=v: H.gemm(H.NT, feat, wih, xg, N, 2048, 3136, flags=H.EPI_OUT_F32, big=v), 2 * N * 2048 * 3136, 0)
+    NBk = 5120                                        # backward window rows (80 steps x 64 sequences)
+    dGk_all = bf(NBk, 2048, scale=0.01)
+    gih = torch.zeros(2048, 3136, device=DEV)
+    dx3 = torch.zeros(NBk, 3136, dtype=torch.bfloat16, device=DEV)
+    for v in (0, 2, 4):                               # N = 3136 = 49 x 64: only 64-wide tiles divide it
+        cases["r2_dwih_tn_v%d" % v] = (lambda v=v: H.gemm(H.TN, dGk_all, feat[:NBk], gih, 2048, 3136, NBk, flags=H.EPI_OUT_F32, big=v), 2 * NBk * 2048 * 3136, 0)
+        cases["r2_dx_nn_v%d" % v] = (lambda v=v: H.gemm(H.NN, dGk_all, wih, dx3, NBk, 3136, 2048, mask=feat[:NBk], flags=H.EPI_MASK, big=v), 2 * NBk * 2048 * 3136, 0)
+    hs_all = bf(NBk, 512)
+    ghh = torch.zeros(2048, 512, device=DEV)
+    for v in (0, 1, 2, 4):
+        cases["r2_dwhh_tn_v%d" % v] = (lambda v=v: H.gemm(H.TN, dGk_all, hs_all, ghh, 2048, 512, NBk, flags=H.EPI_OUT_F32, big=v), 2 * NBk * 2048 * 512, 0)
+    for v in (0, 4):
+        for sp in (2, 4):
+            cases["r2_dwih_tn_v%d_sk%d" % (v, sp)] = (lambda v=v, sp=sp: H.gemm(H.TN, dGk_all, feat[:NBk], gih, 2048, 3136, NBk, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=sp, big=v), 2 * NBk * 2048 * 3136, 0)
     hp, whh = bf(64, 512), bf(2048, 512, scale=0.05)
     xg_t, c0 = torch.randn(64, 2048, device=DEV), torch.zeros(64, 512, device=DEV)
     ho, co = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 512, device=DEV)

@@ -293,3 +293,21 @@ def test_r2d2_engine_persistent_lstm_matches_step_launches():
     assert outs[0][3] == pytest.approx(outs[1][3], rel=3e-2)
     gn0, gn1 = outs[0][2].norm(), outs[1][2].norm()
     assert float((outs[0][2] - outs[1][2]).norm() / gn1) < 5e-2 and float(gn0) > 0
+
+
+def test_r2d2_engine_library_gemm_matches_own_kernels(monkeypatch):
+    """The big plain products of the R2D2 step go to hipBLASLt (ops.hip.lib_gemm); forced on at test size they must
+    give the same Q values, loss and gradient as the hand-written GEMM (both accumulate in fp32)."""
+    from distributed_rl_amd.ops import hip as H
+    outs = []
+    for lib in (True, False):
+        monkeypatch.setattr(H, "LIB_GEMM", lib)
+        monkeypatch.setattr(H, "LIB_GEMM_MIN_FLOP", 0.0)
+        _, cfg, rep, eng = _r2d2_setup(B=16, cap=48, seed=6)
+        eng._forward_backward()
+        torch.cuda.synchronize()
+        outs.append((eng.on.q.clone(), eng.G.flat.clone(), eng.stats()["loss"], eng.on.xg.clone()))
+    torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-2, atol=2e-2)
+    assert outs[0][2] == pytest.approx(outs[1][2], rel=3e-2)
+    assert float((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()) < 2e-2
