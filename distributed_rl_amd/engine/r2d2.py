@@ -21,7 +21,7 @@ Burn-in steps run the same kernels; gradients simply never flow past t = burn_in
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -51,37 +51,55 @@ class SeqNetBuffers:
 
 
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
-                      wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor) -> None:
-    """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over all T*B frames + ONE input-projection GEMM
-    for all steps (throughput-bound)."""
-    N = T * B
-    H.conv_fwd(1, frames, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, N, frame_off)
-    H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, N)
-    H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, N)
-    H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
-    xg = buf.xg.view(N, 4 * Hd)
-    if H.use_lib_gemm(N, 4 * Hd, 3136):        # big plain product: hipBLASLt (see ops.hip.lib_gemm), bias as a second pass
-        H.lib_gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), xg)
+                      wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None) -> None:
+    """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
+    all T) + ONE input-projection GEMM for those steps (throughput-bound)."""
+    t0, t1 = steps if steps is not None else (0, T)
+    r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
+    x = frames if frame_off is not None else frames[r0:r1]
+    fo = frame_off[r0:r1] if frame_off is not None else None
+    a1, a2, a3 = buf.act1[r0:r1], buf.act2[r0:r1], buf.act3[r0:r1]
+    H.conv_fwd(1, x, wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
+    H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n)
+    H.conv_fwd(3, a2, wb.view("conv3.w"), wf.view("conv3.b"), a3, n)
+    if t0 == 0:
+        H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
+    xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
+    if H.use_lib_gemm(n, 4 * Hd, 3136):        # big plain product: hipBLASLt (see ops.hip.lib_gemm), bias as a second pass
+        H.lib_gemm(H.NT, a3, wb.view("lstm.w_ih"), xg)
         xg.add_(bsum)
     else:
-        H.gemm(H.NT, buf.act3, wb.view("lstm.w_ih"), xg, N, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=N >= 1024)
+        H.gemm(H.NT, a3, wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
+
+
+def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, persistent: bool,
+                   steps: Optional[Tuple[int, int]] = None) -> None:
+    """The recurrence over time steps ``steps`` (default: all T) from the state in buf.hs[t0] / buf.cs[t0]: one persistent
+    launch, or one launch of the EPI_LSTM GEMM per step; latency-bound."""
+    t0, t1 = steps if steps is not None else (0, T)
+    w_hh = wb.view("lstm.w_hh")
+    if persistent:
+        gates = buf.gates[t0:t1] if buf.gates is not None else None
+        H.lstm_seq_fwd([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates)], t1 - t0, B, Hd, buf.sync, buf.err)
+    else:
+        for t in range(t0, t1):
+            H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
+                        buf.gates[t] if buf.gates is not None else None)
+
+
+def seq_heads(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers) -> None:
+    """Time-batched FC + dueling head over all T*B LSTM outputs."""
+    N = T * B
+    H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
+           flags=H.EPI_RELU, big=N >= 1024)
+    H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
 
 
 def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers,
                           persistent: bool) -> None:
-    """The recurrence from the state in buf.hs[0] / buf.cs[0] (one persistent launch, or T launches of the EPI_LSTM
-    GEMM; latency-bound) + time-batched FC and dueling head."""
-    N = T * B
-    w_hh = wb.view("lstm.w_hh")
-    if persistent:
-        H.lstm_seq_fwd([(buf.xg, w_hh, buf.hs, buf.cs, buf.gates)], T, B, Hd, buf.sync, buf.err)
-    else:
-        for t in range(T):
-            H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
-                        buf.gates[t] if buf.gates is not None else None)
-    H.gemm(H.NT, buf.hs[1:].view(N, Hd), wb.view("fc1.w"), buf.h2, N, 1024, Hd, bias=wf.view("fc1.b"),
-           flags=H.EPI_RELU, big=N >= 1024)
-    H.head_fwd(buf.h2, wb.view("adv2.w"), None, wb.view("val2.w"), wf.view("val2.b"), buf.q)
+    """Recurrence over all T steps + heads."""
+    seq_recurrence(T, B, Hd, wb, buf, persistent)
+    seq_heads(T, B, Hd, wb, wf, buf)
 
 
 def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
@@ -96,7 +114,7 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
 class R2D2Engine:
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 1):
+                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 1, fwd_chunks: int = 2):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = dev = torch.device(device)
         self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
@@ -143,6 +161,7 @@ class R2D2Engine:
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
+        self.fwd_chunks = max(1, int(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks)))
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
@@ -171,10 +190,32 @@ class R2D2Engine:
         # overlap only partly.
         H.gather_state(r.h0, r.idx, None, self.on.hs[0])
         H.gather_state(r.c0, r.idx, self.on.cs[0], None)
-        seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on)
-        with fj.fork(0):                                            # target net: queued behind the online torso
-            self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
-        seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm)
+        if self.fwd_chunks > 1 and fj.enabled:
+            # PIPELINED over time chunks: the torso of chunk k+1 (throughput-bound, all CUs) runs while the recurrences
+            # of chunk k (latency-bound, 32 workgroups per net) chase it on two side streams, so the forward costs about
+            # one recurrence + one torso chunk instead of two torsos + one recurrence. Measured (64 x 120, MI355X): 4.03 /
+            # 3.76 / 3.87 / 4.49 / 4.47 ms per step for 1 / 2 / 4 / 6 / 8 chunks (every chunk restarts the persistent
+            # kernel - W_hh slice back into LDS - and the recurrence steps slow down under the torso's memory traffic)
+            H.gather_state(r.h0, r.idx, None, self.tg.hs[0])
+            H.gather_state(r.c0, r.idx, self.tg.cs[0], None)
+            csz = (T + self.fwd_chunks - 1) // self.fwd_chunks
+            for t0 in range(0, T, csz):
+                st_ = (t0, min(T, t0 + csz))
+                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_)
+                with fj.fork(0):
+                    seq_recurrence(T, B, Hd, self.Pb, self.on, self.persistent_lstm, steps=st_)
+                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_)
+                with fj.fork(2):
+                    seq_recurrence(T, B, Hd, self.Tb, self.tg, self.persistent_lstm, steps=st_)
+            with fj.fork(0):
+                seq_heads(T, B, Hd, self.Pb, self.P, self.on)
+            with fj.fork(2):
+                seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
+        else:
+            seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on)
+            with fj.fork(0):                                        # target net: queued behind the online torso
+                self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
+            seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm)
         H.is_weights(r.prio, self.st, self.w)
         fj.join()
         H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,
@@ -238,10 +279,12 @@ class R2D2Engine:
         else:
             H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
         if self.fused_bwd:                                          # dX + dW + db of a conv layer = one launch (k_multi)
-            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), d2, n, splits=sp)
+            # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
+            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), d2, n, splits=sp,
+                       variant=4 if n >= 2048 else None)
             H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), d1, n, splits=sp)
             H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
-                       frame_off=r.frame_off[r0 + lo:r0 + hi], splits=2 * sp)
+                       frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
             return
         H.conv_wgrad(3, a2, d3, G.view("conv3.w"), n, splits=sp)
         H.colsum(d3, G.view("conv3.b"), n * 49, 64)

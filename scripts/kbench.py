@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--splits", type=int, default=32, help="split-K count of the fused conv backward cases")
     args = ap.parse_args()
     global EAGER
     EAGER = args.eager
@@ -131,11 +132,12 @@ def main():
     hq = bf(B, 1024)
     for v in range(6):
         cases["fc1_bwd_fused_v%d" % v] = (lambda v=v: H.fc_bwd(dh, a3[:B], wfc, gfc, dbh, d3, B, 1024, 3136, head=(dq, hq, gwa, gba, gwv, gbv), variant=v), 4 * B * 1024 * 3136, 0)
+    SP = args.splits
     for v in range(6):
-        cases["conv3_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(3, a2[:B], d3v, w3, g3, db, dx2, B, splits=32, variant=v), 2 * B * (49 + 81) * 64 * 576, 0)
-        cases["conv2_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(2, a1[:B], d2v, w2, g2, db, dx1, B, splits=32, variant=v), 2 * B * 81 * 64 * 512 + 2 * B * 400 * 32 * 256, 0)
+        cases["conv3_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(3, a2[:B], d3v, w3, g3, db, dx2, B, splits=SP, variant=v), 2 * B * (49 + 81) * 64 * 576, 0)
+        cases["conv2_bwd_fused_v%d" % v] = (lambda v=v: H.conv_bwd(2, a1[:B], d2v, w2, g2, db, dx1, B, splits=SP, variant=v), 2 * B * 81 * 64 * 512 + 2 * B * 400 * 32 * 256, 0)
     db1 = torch.zeros(32, device=DEV)
-    cases["conv1_bwd_fused"] = (lambda: H.conv_bwd(1, x, d1v, None, g1, db1, None, B, frame_off=foff, splits=128), 2 * B * 400 * 32 * 256, 0)
+    cases["conv1_bwd_fused"] = (lambda: H.conv_bwd(1, x, d1v, None, g1, db1, None, B, frame_off=foff, splits=4 * SP), 2 * B * 400 * 32 * 256, 0)
     # R2D2-sized GEMMs
     N = 7680
     feat = bf(N, 3136)
