@@ -87,6 +87,7 @@ struct DenseOp {
     static constexpr bool HAS_CLASS = false;
     typedef uint4 raw_t;     // 8 bf16
     __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ __forceinline__ const void* gptr(off_t off) const { return p + off; }
     __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
     __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
 };
@@ -130,6 +131,11 @@ struct ConvOp {
         if constexpr (U8_) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(x) + off);
         else return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + off);
     }
+    __device__ __forceinline__ const void* gptr(off_t off) const {
+        if constexpr (U8_) return reinterpret_cast<const uint8_t*>(x) + off;
+        else return reinterpret_cast<const bf16_t*>(x) + off;
+    }
+    static constexpr bool IS_U8 = U8_;
     __device__ static __forceinline__ raw_t zero_raw() {
         if constexpr (U8_) return make_uint2(0, 0);
         else return make_uint4(0, 0, 0, 0);
@@ -193,6 +199,7 @@ struct DgradOp {          // A operand (normal orientation): rows = pixels of on
     }
     typedef uint4 raw_t;
     __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ __forceinline__ const void* gptr(off_t off) const { return p + off; }
     __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
     __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
 };
@@ -216,6 +223,7 @@ struct WdgradOp {         // B operand (transposed orientation, memory rows = k)
     __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
     typedef uint4 raw_t;
     __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
+    __device__ __forceinline__ const void* gptr(off_t off) const { return p + off; }
     __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0, 0, 0, 0); }
     __device__ static __forceinline__ uint4 to_bf16x8(raw_t v) { return v; }
 };
@@ -318,6 +326,106 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
     }
 }
 
+// XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and every XCD has its own 4 MB L2:
+// with the plain (bx, by) order the 32 tiles an XCD works on at a time are spread over the whole output and pull (almost)
+// ALL of A and B through that L2 (FC1 forward, 16 x 16 tiles: 7.2 MB per XCD). Re-ordered, the tiles of one XCD are
+// consecutive ids of a grouped order (GROUP_M tile rows, column-major inside the group - 4 x 8 tiles for a 16 x 16 grid),
+// so tiles that share operand panels share an L2. Bijective for any grid (guide 5.3 "XCD swizzle must be bijective").
+#ifndef DRL_GEMM_XCD_REMAP
+#define DRL_GEMM_XCD_REMAP 1
+#endif
+__device__ __forceinline__ void tile_remap(int& bx, int& by, int gx, int gy) {
+    if (!DRL_GEMM_XCD_REMAP || gx < 2 || gy < 2) return;
+    constexpr int NXCD = 8, GROUP_M = 4;
+    const int n = gx * gy, id = by * gx + bx;
+    const int xcd = id % NXCD, q = n / NXCD, r = n % NXCD;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / NXCD;
+    const int gsz = GROUP_M * gx, grp = t / gsz, first = grp * GROUP_M, gm = min(gy - first, GROUP_M), in = t - grp * gsz;
+    by = first + in % gm;
+    bx = in / gm;
+}
+
+// Epilogue shared by the register-ring and the LDS-DMA mainloops: lane holds C[m][n..n+3] of each of its MFMA tiles.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const Epilogue& ep, int m0, int n0, int Mo,
+                                              int No, uint8_t* smem, int tid, int lane, int wm, int wn) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    const int flags = ep.flags;
+    if (flags & EPI_ATOMIC) {
+        // split-K accumulation: stage the f32 tile through LDS so every atomic wave-instruction adds 256 CONTIGUOUS
+        // bytes of one output row (full-rate shape, guide Guideline 12); the fragment layout itself (16 rows x 4
+        // scattered dwords per instruction) measured ~6x slower and dominated the weight-gradient kernels.
+        constexpr int LDC = BN + 4;
+        float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ml = wm * (BM / WM) + i * 16 + (lane & 15), nl = wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<float4*>(tile + ml * LDC + nl) =
+                    make_float4(acc[i][j][0] * ep.scale, acc[i][j][1] * ep.scale, acc[i][j][2] * ep.scale, acc[i][j][3] * ep.scale);
+            }
+        __syncthreads();
+        float* C = reinterpret_cast<float*>(ep.C);
+        for (int idx = tid; idx < BM * BN; idx += NTHREADS) {
+            const int ml = idx / BN, nl = idx - ml * BN;
+            if (m0 + ml < Mo) atomicAdd(C + (long long)(m0 + ml) * ep.ldc + n0 + nl, tile[ml * LDC + nl]);
+        }
+        return;
+    }
+
+    // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = tile col 4*(lane>>4)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
+        if (m >= Mo) continue;
+        long long mrow = m;                  // row of C / mask in memory
+        if (flags & EPI_REMAP) {
+            const int b = m / (ep.rm_hc * ep.rm_wc), rem = m - b * (ep.rm_hc * ep.rm_wc), yy = rem / ep.rm_wc, xx = rem - yy * ep.rm_wc;
+            mrow = ((long long)b * ep.rm_h + ep.rm_s * yy + ep.rm_py) * ep.rm_w + ep.rm_s * xx + ep.rm_px;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
+            if (n >= No) continue;
+            float v[4] = {acc[i][j][0] * ep.scale, acc[i][j][1] * ep.scale, acc[i][j][2] * ep.scale, acc[i][j][3] * ep.scale};
+            if (ep.bias) {
+                float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (flags & EPI_LSTM) {
+                const float4 x = *reinterpret_cast<const float4*>(ep.xg + (long long)m * ep.ldxg + n);
+                const int H = No >> 2, u = n >> 2;
+                const float ig = sigmoidf_(v[0] + x.x), fg = sigmoidf_(v[1] + x.y), gg = tanhf_(v[2] + x.z), og = sigmoidf_(v[3] + x.w);
+                const float c = fg * ep.c_prev[(long long)m * H + u] + ig * gg;
+                ep.c_out[(long long)m * H + u] = c;
+                ep.h_out[(long long)m * H + u] = f2bf(og * tanhf_(c));
+                if (ep.gates_out)
+                    *reinterpret_cast<uint2*>(ep.gates_out + (long long)m * No + n) = make_uint2(pack_bf2(ig, fg), pack_bf2(gg, og));
+                continue;
+            }
+            if (flags & EPI_RELU) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+            }
+            if (flags & EPI_MASK) {
+                uint2 mk = *reinterpret_cast<const uint2*>(ep.mask + mrow * ep.ldmask + n);
+                // bf16 > 0  <=>  sign bit clear and not zero
+                uint32_t e[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (e[t] == 0 || (e[t] & 0x8000u)) v[t] = 0.f;
+            }
+            if (flags & EPI_OUT_F32) {
+                float* c = reinterpret_cast<float*>(ep.C) + mrow * ep.ldc + n;
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(ep.C) + mrow * ep.ldc + n;
+                *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The kernel. grid = (tiles_n, tiles_m, splits). Contraction length Kc is processed in BKT tiles; split z handles
 // tiles [z*kt_per, min((z+1)*kt_per, nkt)).
@@ -331,7 +439,8 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
 // as one of several bodies of a horizontally fused launch (k_multi, below).
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
 __device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep, int bx, int by,
-                                          int bz, uint8_t* smem) {
+                                          int bz, int gx, int gy, uint8_t* smem) {
+    tile_remap(bx, by, gx, gy);
     constexpr bool CLASSES = AOp::HAS_CLASS;     // bz = stride-parity class of an implicit dgrad (no split-K)
     static_assert(AOp::HAS_CLASS == BOp::HAS_CLASS, "both operands must agree on classes");
     if constexpr (CLASSES) {
@@ -413,86 +522,153 @@ __device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int 
     // tail: fewer than D tiles left
     static_for<0, D>([&](auto sc) __attribute__((always_inline)) { if (kt + decltype(sc)::value < kt1) substep(sc, kt + decltype(sc)::value); });
 
-    const int flags = ep.flags;
-    if (flags & EPI_ATOMIC) {
-        // split-K accumulation: stage the f32 tile through LDS so every atomic wave-instruction adds 256 CONTIGUOUS
-        // bytes of one output row (full-rate shape, guide Guideline 12); the fragment layout itself (16 rows x 4
-        // scattered dwords per instruction) measured ~6x slower and dominated the weight-gradient kernels.
-        constexpr int LDC = BN + 4;
-        float* tile = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ml = wm * (BM / WM) + i * 16 + (lane & 15), nl = wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<float4*>(tile + ml * LDC + nl) =
-                    make_float4(acc[i][j][0] * ep.scale, acc[i][j][1] * ep.scale, acc[i][j][2] * ep.scale, acc[i][j][3] * ep.scale);
-            }
-        __syncthreads();
-        float* C = reinterpret_cast<float*>(ep.C);
-        for (int idx = tid; idx < BM * BN; idx += NTHREADS) {
-            const int ml = idx / BN, nl = idx - ml * BN;
-            if (m0 + ml < Mo) atomicAdd(C + (long long)(m0 + ml) * ep.ldc + n0 + nl, tile[ml * LDC + nl]);
-        }
-        return;
-    }
+    gemm_epilogue<BM, BN, WM, WN>(acc, ep, m0, n0, Mo, No, smem, tid, lane, wm, wn);
+}
 
-    // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = tile col 4*(lane>>4)
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA mainloop (global_load_lds_dwordx4): tiles go global -> LDS with NO register staging.
+// ---------------------------------------------------------------------------------------------------
+// The register ring above keeps D-1 tiles in flight at a cost of 16 VGPRs per tile and ~46 vector instructions per
+// K-tile (address selects, validity masks, ds_write). Here a K-tile is NCH_A + NCH_B `global_load_lds_dwordx4` per
+// thread into one of NS LDS stages; NS - 1 tiles are in flight whatever the register budget.
+//   * The LDS destination of an LDS-DMA is wave-uniform base + lane * 16, i.e. the LDS image is LINEAR in the chunk id
+//     (tid + i * 256). The XOR swizzles of nrm_off / tr_off permute chunks inside a row only, so they are applied on the
+//     SOURCE side: LDS slot (r, s) is fed from global chunk (r, s ^ f(r)); the fragment reads are unchanged.
+//   * A masked chunk (row / k out of range, dgrad border tap, tile past the end of the K range) is fetched from a
+//     zeroed 64-byte page instead of its real address: still branch-free, and the number of DMAs per tile is CONSTANT,
+//     so one counted `s_waitcnt vmcnt(LPT * (NS - 2))` is right for every iteration, tail included.
+//   * Ordering (guide "Read a staged buffer one phase AFTER the wait that retires it"): every wave waits for ITS DMAs of
+//     tile kt, then a raw s_barrier makes all of them visible; the DMAs of tile kt + NS - 1 reuse the stage read in
+//     iteration kt - 1 and are issued after that barrier, which every wave reaches only after its MFMAs of kt - 1.
+__device__ uint4 g_zero_page[4];
+
+typedef __attribute__((address_space(1))) const void* gas_cptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+template <int OUT, bool TR, class Op>
+struct GldsTile {
+    static constexpr int BKT = 64;
+    static constexpr int ROWS = TR ? BKT : OUT, COLS = TR ? OUT : BKT, CPR = COLS / 8;
+    static constexpr int NCH = (ROWS * CPR) / NTHREADS, BYTES = ROWS * COLS * 2;
+    static_assert(NCH >= 1 && (ROWS * CPR) % NTHREADS == 0, "tile too small for 256 threads");
+    typename Op::off_t base[TR ? 1 : NCH];
+    unsigned ok;
+    __device__ __forceinline__ void init(const Op& op, int out0, int tid) {
+        ok = 0;
+        if constexpr (!TR) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
-        if (m >= Mo) continue;
-        long long mrow = m;                  // row of C / mask in memory
-        if (flags & EPI_REMAP) {
-            const int b = m / (ep.rm_hc * ep.rm_wc), rem = m - b * (ep.rm_hc * ep.rm_wc), yy = rem / ep.rm_wc, xx = rem - yy * ep.rm_wc;
-            mrow = ((long long)b * ep.rm_h + ep.rm_s * yy + ep.rm_py) * ep.rm_w + ep.rm_s * xx + ep.rm_px;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
-            if (n >= No) continue;
-            float v[4] = {acc[i][j][0] * ep.scale, acc[i][j][1] * ep.scale, acc[i][j][2] * ep.scale, acc[i][j][3] * ep.scale};
-            if (ep.bias) {
-                float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (flags & EPI_LSTM) {
-                const float4 x = *reinterpret_cast<const float4*>(ep.xg + (long long)m * ep.ldxg + n);
-                const int H = No >> 2, u = n >> 2;
-                const float ig = sigmoidf_(v[0] + x.x), fg = sigmoidf_(v[1] + x.y), gg = tanhf_(v[2] + x.z), og = sigmoidf_(v[3] + x.w);
-                const float c = fg * ep.c_prev[(long long)m * H + u] + ig * gg;
-                ep.c_out[(long long)m * H + u] = c;
-                ep.h_out[(long long)m * H + u] = f2bf(og * tanhf_(c));
-                if (ep.gates_out)
-                    *reinterpret_cast<uint2*>(ep.gates_out + (long long)m * No + n) = make_uint2(pack_bf2(ig, fg), pack_bf2(gg, og));
-                continue;
-            }
-            if (flags & EPI_RELU) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
-            }
-            if (flags & EPI_MASK) {
-                uint2 mk = *reinterpret_cast<const uint2*>(ep.mask + mrow * ep.ldmask + n);
-                // bf16 > 0  <=>  sign bit clear and not zero
-                uint32_t e[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) if (e[t] == 0 || (e[t] & 0x8000u)) v[t] = 0.f;
-            }
-            if (flags & EPI_OUT_F32) {
-                float* c = reinterpret_cast<float*>(ep.C) + mrow * ep.ldc + n;
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(ep.C) + mrow * ep.ldc + n;
-                *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            for (int i = 0; i < NCH; ++i) {
+                const int r = out0 + (tid + i * NTHREADS) / CPR;
+                base[i] = op.row_base(r);
+                ok |= (op.row_ok(r) ? 1u : 0u) << i;
             }
         }
     }
+    __device__ __forceinline__ void issue(const Op& op, int out0, int k0, int Kc, int tid, int wave, uint8_t* lds, bool active) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + i * NTHREADS, r = id / CPR, s = id % CPR;
+            int c;                                   // source chunk column of LDS slot (r, s)
+            if constexpr (TR) {
+                constexpr int U = OUT / 16;
+                constexpr int SH = (U >= 8) ? 0 : (U == 4 ? 1 : (U == 2 ? 2 : 3));
+                c = ((((s >> 1) ^ ((r >> SH) & (U - 1))) & (U - 1)) << 1) | (s & 1);
+            } else {
+                c = s ^ ((r >> 1) & 7);
+            }
+            const int kidx = TR ? k0 + r : k0 + c * 8;
+            bool v = active && kidx < Kc;
+            typename Op::off_t rb, off;
+            if constexpr (TR) { rb = op.row_base(kidx); v = v && op.row_ok(kidx); off = rb + (typename Op::off_t)op.col_off(out0 + c * 8); }
+            else { rb = base[i]; v = v && ((ok >> i) & 1u) && op.pair_ok(rb, kidx); off = op.addr(rb, kidx); }
+            const void* src = v ? op.gptr(off) : (const void*)g_zero_page;
+            uint8_t* dst = lds + (i * NTHREADS + wave * 64) * 16;          // wave-uniform; the DMA adds lane * 16
+            __builtin_amdgcn_global_load_lds((gas_cptr)src, (las_ptr)dst, 16, 0, 0);
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, int NS, class AOp, class BOp>
+__device__ __forceinline__ void gemm_tile_glds(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep, int bx, int by,
+                                               int bz, int gx, int gy, uint8_t* smem) {
+    tile_remap(bx, by, gx, gy);
+    constexpr int BKT = 64;
+    constexpr bool CLASSES = AOp::HAS_CLASS;
+    static_assert(AOp::HAS_CLASS == BOp::HAS_CLASS, "both operands must agree on classes");
+    static_assert(WM * WN == 4 && NS >= 3, "4 waves, >= 3 LDS stages");
+    if constexpr (CLASSES) {
+        aop.set_class(bz);
+        bop.set_class(bz);
+        ep.rm_py = aop.py;
+        ep.rm_px = aop.px;
+    }
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    typedef GldsTile<BM, A_TR, AOp> GA;
+    typedef GldsTile<BN, B_TR, BOp> GB;
+    constexpr int STAGE = GA::BYTES + GB::BYTES, LPT = GA::NCH + GB::NCH;
+    static_assert(LPT * (NS - 2) <= 63, "vmcnt field");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int nkt = (Kc + BKT - 1) / BKT;
+    const int kt0 = CLASSES ? 0 : bz * kt_per, kt1 = min(kt0 + kt_per, nkt);
+    if (kt0 >= kt1) return;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    GA ga;
+    GB gb;
+    ga.init(aop, m0, tid);
+    gb.init(bop, n0, tid);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        ga.issue(aop, m0, (kt0 + s) * BKT, Kc, tid, wave, smem + s * STAGE, kt0 + s < kt1);
+        gb.issue(bop, n0, (kt0 + s) * BKT, Kc, tid, wave, smem + s * STAGE + GA::BYTES, kt0 + s < kt1);
+    }
+    int st = 0, st_fill = NS - 1;                 // stage of tile kt / stage the tile kt + NS - 1 goes to
+    for (int kt = kt0; kt < kt1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NS - 2)) : "memory");     // this wave's DMAs of tile kt have landed
+        __builtin_amdgcn_s_barrier();                                              // ... and everybody else's
+        ga.issue(aop, m0, (kt + NS - 1) * BKT, Kc, tid, wave, smem + st_fill * STAGE, kt + NS - 1 < kt1);
+        gb.issue(bop, n0, (kt + NS - 1) * BKT, Kc, tid, wave, smem + st_fill * STAGE + GA::BYTES, kt + NS - 1 < kt1);
+        const uint8_t* As = smem + st * STAGE;
+        const uint8_t* Bs = As + GA::BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 32; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_TR>(As, wm * (BM / WM) + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_TR>(Bs, wn * (BN / WN) + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, bf[j]),
+                                                                        __builtin_bit_cast(mfma_bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+        st_fill = st_fill + 1 == NS ? 0 : st_fill + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-page DMAs of the tail still target LDS
+    __syncthreads();
+    gemm_epilogue<BM, BN, WM, WN>(acc, ep, m0, n0, Mo, No, smem, tid, lane, wm, wn);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, int NS, class AOp, class BOp>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_glds(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    gemm_tile_glds<BM, BN, WM, WN, A_TR, B_TR, NS, AOp, BOp>(aop, bop, Mo, No, Kc, kt_per, ep, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, smem);
 }
 
 template <int BM, int BN, int BKT, int WM, int WN, bool A_TR, bool B_TR, int D, class AOp, class BOp>
 __global__ __launch_bounds__(NTHREADS) void k_gemm(AOp aop, BOp bop, int Mo, int No, int Kc, int kt_per, Epilogue ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(aop, bop, Mo, No, Kc, kt_per, ep, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(aop, bop, Mo, No, Kc, kt_per, ep, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, smem);
 }
 
 // grid / split / LDS plan shared by the stand-alone launch and the fused launches; returns 0 or a negative error
@@ -521,6 +697,27 @@ static int launch(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits
     size_t lds;
     if (int rc = plan_gemm<BM, BN, BKT>(Mo, No, Kc, splits, ep, classes, &kt_per, &grid, &lds)) return rc;
     auto kern = k_gemm<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>;
+    if (lds > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -6;
+            once = true;
+        }
+    }
+    kern<<<grid, NTHREADS, lds, s>>>(a, b, Mo, No, Kc, kt_per, ep);
+    return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, int NS, class AOp, class BOp>
+static int launch_glds(const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, hipStream_t s,
+                       int classes = 0) {
+    int kt_per;
+    dim3 grid;
+    size_t lds;
+    if (int rc = plan_gemm<BM, BN, 64>(Mo, No, Kc, splits, ep, classes, &kt_per, &grid, &lds)) return rc;
+    lds = (size_t)NS * (BM + BN) * 64 * 2;
+    if ((ep.flags & EPI_ATOMIC) && lds < (size_t)BM * (BN + 4) * 4) lds = (size_t)BM * (BN + 4) * 4;
+    auto kern = k_gemm_glds<BM, BN, WM, WN, A_TR, B_TR, NS, AOp, BOp>;
     if (lds > 64 * 1024) {
         static bool once = false;
         if (!once) {
@@ -562,6 +759,12 @@ static int dense_dispatch(int variant, const DenseOp& A, const DenseOp& B, int M
         case 4: return launch<128, 64, 128, 2, 2, A_TR, B_TR, 2>(A, B, M, N, K, splits, ep, s);
         case 5: return launch<64, 32, 64, 4, 1, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
         case 6: return launch<32, 64, 64, 1, 4, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
+        // LDS-DMA mainloop (no register staging): tile / number of LDS stages
+        case 10: return launch_glds<64, 64, 2, 2, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
+        case 11: return launch_glds<64, 64, 2, 2, A_TR, B_TR, 6>(A, B, M, N, K, splits, ep, s);
+        case 12: return launch_glds<128, 128, 2, 2, A_TR, B_TR, 3>(A, B, M, N, K, splits, ep, s);
+        case 13: return launch_glds<128, 64, 2, 2, A_TR, B_TR, 4>(A, B, M, N, K, splits, ep, s);
+        case 14: return launch_glds<64, 64, 2, 2, A_TR, B_TR, 8>(A, B, M, N, K, splits, ep, s);
     }
     return -7;
 }
@@ -574,7 +777,7 @@ DRL_API int drl_gemm(int mode, int variant, const void* a, long long lda, const 
     Epilogue ep = make_epi(C, ldc, bias, mask, ldmask, scale, flags);
     const bf16_t* pa = (const bf16_t*)a;
     const bf16_t* pb = (const bf16_t*)b;
-    const int bm = (variant == 1 || variant == 4) ? 128 : (variant == 6 ? 32 : 64);
+    const int bm = (variant == 1 || variant == 4 || variant == 12 || variant == 13) ? 128 : (variant == 6 ? 32 : 64);
     if (mode == 0) {
         if (K % 8) return -5;
         DenseOp A{pa, lda, M}, B{pb, ldb, N};
@@ -595,7 +798,8 @@ DRL_API int drl_gemm(int mode, int variant, const void* a, long long lda, const 
 // layer 1: x = uint8 frames (optionally through frame_off byte offsets), W [32][256];  layer 2: W [64][512];  layer 3: W [64][576]
 DRL_API int drl_conv_fwd(int layer, const void* x, const long long* frame_off, int frames, const void* w, const float* bias,
                          void* out, int relu, hipStream_t s) {
-    const int fl = relu ? EPI_RELU : 0;
+    const int fl = (relu & 1) ? EPI_RELU : 0;
+    const int variant = relu >> 8;     // layers 2 / 3: 0 = register ring | 1..3 = LDS-DMA mainloop (tile / stages), tuning hook
     if (layer == 1) {
         DenseOp B{(const bf16_t*)w, Conv1Op::K, 32};
         const int rows = frames * Conv1Op::OH * Conv1Op::OW;
@@ -609,11 +813,19 @@ DRL_API int drl_conv_fwd(int layer, const void* x, const long long* frame_off, i
     } else if (layer == 2) {
         Conv2Op A{x, frame_off, frames * Conv2Op::OH * Conv2Op::OW};
         DenseOp B{(const bf16_t*)w, Conv2Op::K, 64};
-        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv2Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
+        const Epilogue ep = make_epi(out, 64, bias, nullptr, 0, 1.0f, fl);
+        if (variant == 1) return launch_glds<128, 64, 2, 2, false, false, 3>(A, B, A.rows, 64, Conv2Op::K, 1, ep, s);
+        if (variant == 2) return launch_glds<128, 64, 2, 2, false, false, 4>(A, B, A.rows, 64, Conv2Op::K, 1, ep, s);
+        if (variant == 3) return launch_glds<64, 64, 2, 2, false, false, 4>(A, B, A.rows, 64, Conv2Op::K, 1, ep, s);
+        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv2Op::K, 1, ep, s);
     } else if (layer == 3) {
         Conv3Op A{x, frame_off, frames * Conv3Op::OH * Conv3Op::OW};
         DenseOp B{(const bf16_t*)w, Conv3Op::K, 64};
-        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv3Op::K, 1, make_epi(out, 64, bias, nullptr, 0, 1.0f, fl), s);
+        const Epilogue ep = make_epi(out, 64, bias, nullptr, 0, 1.0f, fl);
+        if (variant == 1) return launch_glds<128, 64, 2, 2, false, false, 3>(A, B, A.rows, 64, Conv3Op::K, 1, ep, s);
+        if (variant == 2) return launch_glds<128, 64, 2, 2, false, false, 4>(A, B, A.rows, 64, Conv3Op::K, 1, ep, s);
+        if (variant == 3) return launch_glds<64, 64, 2, 2, false, false, 4>(A, B, A.rows, 64, Conv3Op::K, 1, ep, s);
+        return launch<128, 64, 64, 2, 2, false, false, 2>(A, B, A.rows, 64, Conv3Op::K, 1, ep, s);
     }
     return -1;
 }
@@ -711,7 +923,7 @@ struct GemmBody {
     struct Args { AOp a; BOp b; int Mo, No, Kc, kt_per, gx, gy; Epilogue ep; };
     static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
         const int bx = block % g.gx, r = block / g.gx, by = r % g.gy, bz = r / g.gy;
-        gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(g.a, g.b, g.Mo, g.No, g.Kc, g.kt_per, g.ep, bx, by, bz, smem);
+        gemm_tile<BM, BN, BKT, WM, WN, A_TR, B_TR, D, AOp, BOp>(g.a, g.b, g.Mo, g.No, g.Kc, g.kt_per, g.ep, bx, by, bz, g.gx, g.gy, smem);
     }
     // fills ``g``; returns the number of workgroups (or a negative error) and raises *lds to what this body needs
     static int plan(Args& g, const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, int classes, size_t* lds) {

@@ -49,7 +49,8 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
     H.conv_fwd(1, x_u8, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
     H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, n)
     H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, n)
-    H.gemm(H.NT, buf.act3, wb.view("fc1.w"), buf.h, n, 1024, 3136, bias=wf.view("fc1.b"), flags=H.EPI_RELU)
+    # FC1: 64x64 tiles, LDS-DMA mainloop with 4 stages (variant 10): 17.6 us vs 20.9 us for the register ring at n = 1024
+    H.gemm(H.NT, buf.act3, wb.view("fc1.w"), buf.h, n, 1024, 3136, bias=wf.view("fc1.b"), flags=H.EPI_RELU, big=H.FC1_FWD_VARIANT)
     H.head_fwd(buf.h, wb.view("adv2.w"), wf.view("adv2.b"), wb.view("val2.w"), wf.view("val2.b"), buf.q, action_out,
                eps, eps_mod, seed, ctr)
 

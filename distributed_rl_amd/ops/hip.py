@@ -17,6 +17,7 @@ EPI_RELU, EPI_OUT_F32, EPI_ATOMIC, EPI_MASK = 1, 2, 4, 8
 NT, NN, TN = 0, 1, 2
 # tile variants of drl_gemm: 0 = 64x64x64 | 1 = 128x128x64 | 2 = 64x64x128 | 3 = 64x64x256 | 4 = 128x64x128
 GEMM_SMALL_VARIANT = 0
+FC1_FWD_VARIANT = 10        # dense-GEMM variant of the Ape-X FC1 forward (see drl_gemm: 10 = 64x64 tiles, LDS-DMA, 4 stages)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -236,6 +237,11 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
 CONV_FWD_DIRECT = (1,)
 
 
+# tiled conv2 / conv3 forward: 0 = register ring, 1..3 = LDS-DMA mainloop (128x64 x 3 stages / 128x64 x 4 / 64x64 x 4).
+# Measured at 1024 frames: conv2 17.5 us ring vs 19.2 / 25.3 / 19.1; conv3 14.3 us ring vs 12.3 / 17.9 / 13.7.
+CONV_FWD_TILED_VARIANT = {2: 0, 3: 1}
+
+
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
              frame_off: Optional[torch.Tensor] = None, relu: bool = True, direct: Optional[bool] = None,
              variant: int = 0) -> None:
@@ -245,8 +251,9 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
         _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
             "conv_fwd_direct")
         return
-    _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out), 1 if relu else 0, _s()),
-        "conv_fwd")
+    tiled = CONV_FWD_TILED_VARIANT.get(layer, 0) if direct is None else variant
+    _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out),
+                                  (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
 
 
 def conv_wgrad(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, frames: int,

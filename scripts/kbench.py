@@ -87,7 +87,10 @@ def main():
             cases["conv1_fwd" + sfx] = (lambda d=d: H.conv_fwd(1, x, w1, b1, a1, F, direct=d >= 0), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
         cases["conv2_fwd" + sfx] = (lambda d=d: H.conv_fwd(2, a1, w2, b2, a2, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
         cases["conv3_fwd" + sfx] = (lambda d=d: H.conv_fwd(3, a2, w3, b3, a3, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
-    for v in (0, 2, 3, 5, 6):
+    for v in (1, 2, 3):
+        cases["conv2_fwd_glds%d" % v] = (lambda v=v: H.conv_fwd(2, a1, w2, b2, a2, F, direct=False, variant=v), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
+        cases["conv3_fwd_glds%d" % v] = (lambda v=v: H.conv_fwd(3, a2, w3, b3, a3, F, direct=False, variant=v), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
+    for v in (0, 2, 3, 5, 6, 10, 11, 13, 14):
         cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
     hf = torch.zeros(F, 1024, device=DEV)
     for sp in (2, 4, 8):
@@ -96,7 +99,7 @@ def main():
     dh = bf(B, 1024, scale=0.01)
     gfc = torch.zeros(1024, 3136, device=DEV)
     d3 = torch.zeros(B, 3136, dtype=torch.bfloat16, device=DEV)
-    for v in (0, 2, 5, 6):
+    for v in (0, 2, 5, 6, 10, 11, 13):
         cases["fc1_dw_tn_v%d" % v] = (lambda v=v: H.gemm(H.TN, dh, a3[:B], gfc, 1024, 3136, B, flags=H.EPI_OUT_F32, big=v), 2 * B * 1024 * 3136, 4 * 1024 * 3136)
         cases["fc1_dx_nn_v%d" % v] = (lambda v=v: H.gemm(H.NN, dh, wfc, d3, B, 3136, 1024, mask=a3[:B], flags=H.EPI_MASK, big=v), 2 * B * 1024 * 3136, 2 * 1024 * 3136)
     d3v = bf(B * 49, 64, scale=0.01)
@@ -143,7 +146,7 @@ def main():
     feat = bf(N, 3136)
     wih = bf(2048, 3136, scale=0.02)
     xg = torch.zeros(N, 2048, device=DEV)
-    for v in (1, 4):
+    for v in (1, 4, 12, 13):
         cases["lstm_igemm_v%d" % v] = (lambda v=v: H.gemm(H.NT, feat, wih, xg, N, 2048, 3136, flags=H.EPI_OUT_F32, big=v), 2 * N * 2048 * 3136, 0)
     NBk = 5120                                        # backward window rows (80 steps x 64 sequences)
     dGk_all = bf(NBk, 2048, scale=0.01)
@@ -185,7 +188,7 @@ def main():
                               2 * 2 * 64 * 2048 * 512 * Ts, 0)
     print("%-18s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
     for name, (fn, flops, byts) in cases.items():
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         us = timeit(fn, 3 if name.startswith("lstm_1") or name.startswith("lstm_seq") else args.reps)
         print("%-18s %10.1f %10.1f %10.1f" % (name, us, flops / us / 1e6, byts / us / 1e3))

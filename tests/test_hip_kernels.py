@@ -357,7 +357,7 @@ def test_gemm_tn_splitk(hip, M, N, K, big, splits):
     torch.testing.assert_close(c.cpu(), ref, rtol=2e-3, atol=2e-3 * (K ** 0.5) * 0.01 + 1e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
 def test_gemm_tile_variants(hip, variant, mode):
     """Every tile variant (BMxBNxBK / ring depth) on a ragged-K, ragged-M problem incl. split-K atomics."""
@@ -400,13 +400,14 @@ def _conv_setup(layer, frames, seed):
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("frames", [1, 7, 96, 700])
-@pytest.mark.parametrize("direct", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("direct", [-1, 0, 1, 2, 3, -2, -3, -4])          # < -1: tiled kernel with the LDS-DMA mainloop
 def test_conv_fwd(hip, layer, frames, direct):
     H = hip
     x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 100 + frames)
     oh = (hw - ks) // s + 1
     out = torch.zeros(frames, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
-    H.conv_fwd(layer, x.to(DEV), w.to(DEV), bias.to(DEV), out, frames, direct=direct >= 0, variant=max(direct, 0))
+    H.conv_fwd(layer, x.to(DEV), w.to(DEV), bias.to(DEV), out, frames, direct=direct >= 0,
+               variant=max(direct, 0) if direct >= -1 else -direct - 1)
     ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=s)).permute(0, 2, 3, 1)
     torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
