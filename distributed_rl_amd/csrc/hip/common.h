@@ -100,5 +100,9 @@ struct StepState {
     float grad_norm;             // last global grad norm (written by the optimizer)
     float max_w;                 // max IS weight of the last batch (pre-normalisation)
     float pad;
+    // max IS weight of the batch being sampled, as float bits (positive floats order like unsigned ints), accumulated
+    // with atomicMax by the sampling kernel: slot [step & 1] belongs to this step, the other one is cleared for the next
+    unsigned wmax_bits[2];
 };
+static_assert(sizeof(StepState) == 64, "StepState is mirrored by ops/hip.py (STEP_STATE_BYTES)");
 

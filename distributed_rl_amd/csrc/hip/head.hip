@@ -115,6 +115,84 @@ __global__ __launch_bounds__(256) void k_head_bwd_dh(const float* __restrict__ d
     d[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// Ape-X TD (td.hip k_apex_td semantics) FUSED with the head's input gradient: one wave per sampled transition computes
+// the double-DQN target, Huber loss, IS weight, dL/dQ row and new priority, then immediately its dh row. The batch-wide
+// max IS weight was accumulated by the sampling kernel (StepState::wmax_bits), so no block-wide reduction and no
+// single-block kernel sits between the forward and the backward any more. grid = ceil(B/16), block = 1024.
+// q_on rows [0,B) = Q_online(s), [B,2B) = Q_online(s'); q_tg rows [0,B) = Q_target(s'); h = online hidden rows of s.
+__global__ __launch_bounds__(1024) void k_apex_td_dh(const float* __restrict__ q_on, const float* __restrict__ q_tg, int B, int A,
+                                                    const int* __restrict__ idx, const int* __restrict__ act,
+                                                    const float* __restrict__ rew, const float* __restrict__ done,
+                                                    const float* __restrict__ p_sampled, StepState* st, float gamma_n, float alpha,
+                                                    float prio_eps, float n_scale, float* __restrict__ dq,
+                                                    float* __restrict__ new_prio, const bf16_t* __restrict__ h,
+                                                    const bf16_t* __restrict__ w_adv, const bf16_t* __restrict__ w_val,
+                                                    bf16_t* __restrict__ dh) {
+    __shared__ float s_loss[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 16 + wave;
+    float lw = 0.f;
+    if (row < B) {
+        const int slot = idx ? idx[row] : row;
+        const int a = act[slot];
+        const float r = rew[slot], d = done[slot], p = p_sampled[row];
+        const float beta = st->beta, total = st->total_prio, N = (float)st->n_items * n_scale;
+        const float wmax = __uint_as_float(st->wmax_bits[st->step & 1]);
+        const float qs = lane < A ? q_on[(long long)row * A + lane] : 0.f;
+        const float qn = lane < A ? q_on[(long long)(B + row) * A + lane] : -3.0e38f;
+        const float qt = lane < A ? q_tg[(long long)row * A + lane] : 0.f;
+        const float mx = wave_max(qn);
+        const int best = __ffsll((long long)__ballot(lane < A && qn == mx)) - 1;          // first max, like torch.argmax
+        const float y = __shfl(qt, best, WAVE) * gamma_n * (1.0f - d) + r;
+        const float diff = __shfl(qs, a, WAVE) - y;
+        const float ad = fabsf(diff);
+        const float hub = ad < 1.0f ? 0.5f * diff * diff : ad - 0.5f;
+        const float w = (p > 0.f && total > 0.f && wmax > 0.f) ? __powf(N * p / total, -beta) / wmax : 0.f;
+        lw = hub * w;
+        const float gsel = fminf(fmaxf(diff, -1.0f), 1.0f) * w / (float)B;
+        const float g = (lane == a) ? gsel : 0.f;
+        if (lane < A) dq[(long long)row * A + lane] = g;
+        if (lane == 0) new_prio[row] = __powf(hub + prio_eps, alpha);
+        // dh row: dval = sum_j dq_j = gsel, dadv_j = dq_j - dval / A   (k_head_bwd_dh)
+        const float dval = gsel;
+        const float dadv_mine = g - dval / (float)A;
+        float hv[16], wv[16], acc[16];
+        load16_bf16(h + (long long)row * (2 * HID) + lane * 16, hv);
+        const bool adv_half = lane < 32;
+        const int k0 = (lane & 31) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float dj = __shfl(dadv_mine, j, WAVE);
+            if (adv_half) {
+                load16_bf16(w_adv + (long long)j * HID + k0, wv);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += dj * wv[i];
+            }
+        }
+        if (!adv_half) {
+            load16_bf16(w_val + k0, wv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = dval * wv[i];
+        }
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = pack_bf2(hv[2 * i] > 0.f ? acc[2 * i] : 0.f, hv[2 * i + 1] > 0.f ? acc[2 * i + 1] : 0.f);
+        uint4* dst = reinterpret_cast<uint4*>(dh + (long long)row * (2 * HID) + lane * 16);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    if (lane == 0) s_loss[wave] = lw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_loss[i];
+        atomicAdd(&st->loss, t / (float)B);                     // zeroed by the sampling kernel of this step
+        if (blockIdx.x == 0) st->max_w = __uint_as_float(st->wmax_bits[st->step & 1]);
+    }
+}
+
 // Weight grads: see head_bwd_body.h. grid = (4, ceil(M/DW_ROWS)); block = 256.
 __global__ __launch_bounds__(256) void k_head_bwd_dw(const float* __restrict__ dq, const bf16_t* __restrict__ h, int M, int A,
                                                     float* __restrict__ gw_adv, float* __restrict__ gb_adv /* may be null */,
@@ -141,5 +219,16 @@ DRL_API int drl_head_bwd(const float* dq, const void* h, int M, int A, const voi
         k_head_bwd_dh<<<(M + 3) / 4, 256, 0, s>>>(dq, (const bf16_t*)h, M, A, (const bf16_t*)w_adv, (const bf16_t*)w_val, (bf16_t*)dh);
     if (parts & 2)
         k_head_bwd_dw<<<dim3(4, (M + DW_ROWS - 1) / DW_ROWS), 256, 0, s>>>(dq, (const bf16_t*)h, M, A, gw_adv, gb_adv, gw_val, gb_val);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_apex_td_dh(const float* q_on, const float* q_tg, int B, int A, const int* idx, const int* act, const float* rew,
+                           const float* done, const float* p_sampled, void* st, float gamma_n, float alpha, float prio_eps,
+                           float n_scale, float* dq, float* new_prio, const void* h, const void* w_adv, const void* w_val, void* dh,
+                           hipStream_t s) {
+    if (B <= 0 || A <= 0 || A > MAX_A) return -1;
+    k_apex_td_dh<<<(B + 15) / 16, 1024, 0, s>>>(q_on, q_tg, B, A, idx, act, rew, done, p_sampled, (StepState*)st, gamma_n, alpha,
+                                               prio_eps, n_scale, dq, new_prio, (const bf16_t*)h, (const bf16_t*)w_adv,
+                                               (const bf16_t*)w_val, (bf16_t*)dh);
     return (int)hipGetLastError();
 }

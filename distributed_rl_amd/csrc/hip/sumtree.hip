@@ -30,26 +30,30 @@ __global__ void k_step_end(StepState* st) {
 }
 
 // One wave per draw.
-__global__ __launch_bounds__(256) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
+__global__ __launch_bounds__(1024) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
                                                int* __restrict__ idx_out, float* __restrict__ prio_out,
                                                const int* __restrict__ gen, int* __restrict__ gen_out,
                                                long long* __restrict__ frame_off, long long frame_bytes,
-                                               const long long* __restrict__ begin_n_items) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;   // whole wave exits together
+                                               const long long* __restrict__ begin_n_items, float is_n_scale) {
+    __shared__ float s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    float w_is = 0.f;                                      // this draw's un-normalised IS weight (lane 0)
+    if (b < B) {                                           // whole waves take the branch together
     Philox ph(seed);
     // fused step_begin (learner engines): the Philox counter of step t is rng_ctr + t + 1 (nobody writes rng_ctr or step
     // while this kernel runs), and wave 0 publishes beta / n_items for the kernels that follow
     unsigned long long ctr = st->rng_ctr;
+    const unsigned long long t = st->step;
     if (begin_n_items) {
-        const unsigned long long t = st->step;
         ctr += t + 1;
         if (b == 0 && lane == 0) {
             st->beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
             st->n_items = *begin_n_items;
+            if (is_n_scale > 0.f) { st->wmax_bits[(t + 1) & 1] = 0u; st->loss = 0.f; }   // next step's slot; loss is atomically summed
         }
     }
+    float top_sum = 0.f;
     uint4 r = ph(ctr, (unsigned long long)b);
     uint32_t rnd[4] = {r.x, r.y, r.z, r.w};
     long long node = 0;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void k_sample(TreeDesc tr, StepState* st, unsi
         float v = tr.base[tr.off[lvl] + node * 64 + lane];
         float incl = wave_scan_incl(v, lane);
         float S = __shfl(incl, 63, WAVE);
-        if (lvl == tr.n_levels - 1 && b == 0 && lane == 0) st->total_prio = S;
+        if (lvl == tr.n_levels - 1) { top_sum = S; if (b == 0 && lane == 0) st->total_prio = S; }
         float u = u01(rnd[k]) * S;
         unsigned long long hit = __ballot(incl > u && v > 0.f);
         unsigned long long nz = __ballot(v > 0.f);
@@ -74,10 +78,27 @@ __global__ __launch_bounds__(256) void k_sample(TreeDesc tr, StepState* st, unsi
         int i = (int)(node < tr.cap ? node : tr.cap - 1);
         idx_out[b] = i;
         prio_out[b] = leaf_p;
+        if (begin_n_items && is_n_scale > 0.f && leaf_p > 0.f && top_sum > 0.f) {
+            // un-normalised IS weight (N p / total)^-beta of this draw -> running max of the batch (consumed by the fused
+            // TD kernel, head.hip k_apex_td_dh, which therefore needs no batch-wide reduction of its own)
+            const float beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
+            w_is = __powf((float)(*begin_n_items) * is_n_scale * leaf_p / top_sum, -beta);
+        }
         if (gen_out) gen_out[b] = gen ? gen[i] : 0;
         if (frame_off) {                                   // byte offsets of s and s' in the frame store
             frame_off[b] = (long long)i * frame_bytes;
             frame_off[B + b] = ((long long)tr.cap + i) * frame_bytes;
+        }
+    }
+    }
+    // one atomicMax per BLOCK: same-address atomics serialise in L2 (~35 ns each), 512 of them doubled this kernel's time
+    if (begin_n_items && is_n_scale > 0.f) {
+        if (lane == 0) s_w[wave] = w_is;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, s_w[i]);
+            if (m > 0.f) atomicMax(&st->wmax_bits[st->step & 1], __float_as_uint(m));
         }
     }
 }
@@ -162,11 +183,12 @@ DRL_API int drl_step_end(void* st, hipStream_t s) {
 DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, long long cap, void* st,
                                unsigned long long seed, int B, int* idx_out, float* prio_out, const int* gen,
                                int* gen_out, long long* frame_off, long long frame_bytes, const long long* begin_n_items,
-                               hipStream_t s) {
+                               float is_n_scale, hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || B <= 0) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
-    k_sample<<<(B + 3) / 4, 256, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes,
-                                        begin_n_items);
+    const int wpb = (begin_n_items && is_n_scale > 0.f) ? 16 : 4;           // waves per block (one atomic per block, see kernel)
+    k_sample<<<(B + wpb - 1) / wpb, wpb * 64, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off,
+                                                     frame_bytes, begin_n_items, is_n_scale);
     return (int)hipGetLastError();
 }
 

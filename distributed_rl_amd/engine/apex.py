@@ -139,21 +139,26 @@ class ApexEngine:
         ``fc1.w`` to the end of the flat buffer (97.6 % of the parameters) is final - multi-GPU runs start its
         all-reduce here, under the conv backward that follows."""
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
-        r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
+        # step_begin fused; G was zeroed by the optimizer. fused_bwd: the sampler also accumulates the max IS weight
+        r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
         with self._fork(0):                                        # target net on s' || online net on [s ; s']
             torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
         torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
         self._join()
-        H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                  cfg.prio_eps, self.dq, self.new_prio, n_scale=self.n_scale)
         G, Pb, on = self.G, self.Pb, self.on
+        if not self.fused_bwd:
+            H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
+                      cfg.prio_eps, self.dq, self.new_prio, n_scale=self.n_scale)
         h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
         hb = (self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
               G.view("val2.w"), G.view("val2.b"))
         if self.fused_bwd:
+            # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)
+            H.apex_td_dh(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
+                         cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh,
+                         n_scale=self.n_scale)
             # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
-            H.head_bwd(*hb, parts=1)                               # dh
             H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
                      head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))
             return

@@ -8,13 +8,14 @@ SIGS = {
     # sumtree.hip
     "drl_step_begin": [P, P, P],
     "drl_step_end": [P, P],
-    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P, P],
+    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P, F, P],
     "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P],
     "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P],
     "drl_gather_rows": [P, P, P, I, I, P],
     "drl_gather_f32": [P, P, P, I, I, P],
     "drl_gather_i32": [P, P, P, I, I, P],
     # td.hip
+    "drl_apex_td_dh": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, P, P, P, P, P, P, P],
     "drl_apex_td": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, I, P, P, P, P, P],
     "drl_is_weights": [P, I, P, F, P, P],
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],

@@ -98,9 +98,11 @@ class TreeLayout:
 def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
                    prio_out: torch.Tensor, gen: Optional[torch.Tensor] = None, gen_out: Optional[torch.Tensor] = None,
                    frame_off: Optional[torch.Tensor] = None, frame_bytes: int = 0,
-                   begin_n_items: Optional[torch.Tensor] = None) -> None:
+                   begin_n_items: Optional[torch.Tensor] = None, is_n_scale: float = 0.0) -> None:
     """``begin_n_items`` (int64 device scalar) fuses step_begin into the sampling kernel: beta / n_items of the step
-    state are refreshed and the Philox counter of step t is rng_ctr + t + 1 (do not also call step_begin then)."""
+    state are refreshed and the Philox counter of step t is rng_ctr + t + 1 (do not also call step_begin then).
+    ``is_n_scale`` > 0 (with begin_n_items) additionally accumulates the batch's max un-normalised IS weight
+    (is_n_scale * N * p / total)^-beta in the step state and clears its loss, as ``apex_td_dh`` expects."""
     B = idx_out.numel()
     _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
     if frame_off is not None:
@@ -108,7 +110,7 @@ def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: 
         assert frame_off.numel() >= 2 * B
     _ck(native.hip().drl_sumtree_sample(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(st), seed, B, _p(idx_out),
                                         _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), frame_bytes, _p(begin_n_items),
-                                        _s()), "sumtree_sample")
+                                        float(is_n_scale), _s()), "sumtree_sample")
 
 
 def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
@@ -147,6 +149,20 @@ def apex_td(q_on, q_tg, idx, act, rew, done, p_sampled, st, gamma_n, alpha, prio
     _ck(native.hip().drl_apex_td(_p(q_on), _p(q_tg), B, A, _p(idx), _p(act), _p(rew), _p(done), _p(p_sampled), _p(st),
                                  gamma_n, alpha, prio_eps, n_scale, 1 if use_is else 0, _p(dq), _p(new_prio), _p(delta_out),
                                  _p(w_out), _s()), "apex_td")
+
+
+def apex_td_dh(q_on, q_tg, idx, act, rew, done, p_sampled, st, gamma_n, alpha, prio_eps, dq, new_prio, h, w_adv, w_val, dh,
+               n_scale: float = 1.0) -> None:
+    """``apex_td`` fused with the dueling head's input gradient (head.hip k_apex_td_dh): one wave per transition, no
+    batch-wide reduction - the max IS weight comes from the sampling kernel (sumtree_sample(..., is_n_scale=n_scale))."""
+    B, A = q_tg.shape
+    assert q_on.shape == (2 * B, A) and dq.shape == (B, A)
+    for t, n in ((q_on, "q_on"), (q_tg, "q_tg"), (rew, "rew"), (done, "done"), (dq, "dq"), (new_prio, "new_prio")):
+        _chk(t, torch.float32, n)
+    _chk(act, torch.int32, "act"); _chk(h, torch.bfloat16, "h"); _chk(dh, torch.bfloat16, "dh")
+    _ck(native.hip().drl_apex_td_dh(_p(q_on), _p(q_tg), B, A, _p(idx), _p(act), _p(rew), _p(done), _p(p_sampled), _p(st),
+                                    gamma_n, alpha, prio_eps, n_scale, _p(dq), _p(new_prio), _p(h), _p(w_adv), _p(w_val),
+                                    _p(dh), _s()), "apex_td_dh")
 
 
 def is_weights(p_sampled, st, w_out, n_scale: float = 1.0) -> None:

@@ -113,11 +113,12 @@ class DevicePER:
             done += k
 
     # ---- sample / update (graph-capturable) -----------------------------------------------------
-    def sample(self, st: torch.Tensor, begin: bool = False) -> None:
+    def sample(self, st: torch.Tensor, begin: bool = False, is_n_scale: float = 0.0) -> None:
         """Draw ``batch_size`` slots ∝ priority into ``self.idx / prio / gen_s / frame_off``. ``begin`` fuses
-        step_begin (beta / n_items refresh, fresh Philox counter) into the sampling kernel."""
+        step_begin (beta / n_items refresh, fresh Philox counter) into the sampling kernel; ``is_n_scale`` > 0 also
+        accumulates the batch's max IS weight there (see ops.hip.sumtree_sample)."""
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
-                         self.frame_bytes, begin_n_items=self.n_items if begin else None)
+                         self.frame_bytes, begin_n_items=self.n_items if begin else None, is_n_scale=is_n_scale)
 
     def update(self, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None) -> None:
         """Write back priorities of the last sample; slots overwritten since are skipped (generation check).

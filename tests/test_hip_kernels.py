@@ -182,6 +182,44 @@ def test_apex_td(hip, B, A):
     assert s["loss"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
 
 
+@pytest.mark.parametrize("B,A", [(512, 4), (50, 18), (33, 6)])
+def test_apex_td_dh_fused_matches_td_plus_head_bwd(hip, B, A):
+    """TD + head input gradient in one launch, max IS weight from the sampling kernel, against the single-block TD
+    kernel followed by head_bwd(parts=1)."""
+    H = hip
+    cap = 5000
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    g = torch.Generator().manual_seed(B * 7 + A)
+    H.sumtree_ingest(tree, lay, 0, (torch.rand(cap, generator=g) ** 3 + 1e-3).to(DEV), None, torch.zeros(cap, dtype=torch.int32, device=DEV))
+    st = H.new_step_state(DEV, 0.4, 100)
+    n_items = torch.tensor([cap], dtype=torch.int64, device=DEV)
+    idx, p = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, device=DEV)
+    act = torch.randint(0, A, (cap,), generator=g).int().to(DEV)
+    rew, done = torch.randn(cap, generator=g).to(DEV), (torch.rand(cap, generator=g) < 0.1).float().to(DEV)
+    q_on, q_tg = (torch.randn(2 * B, A, generator=g) * 2).to(DEV), (torch.randn(B, A, generator=g) * 2).to(DEV)
+    q_on[B:B + 5] = 1.25                                            # ties in the argmax: the first action wins
+    hq = bf(torch.relu(torch.randn(B, 1024, generator=g))).to(DEV)
+    w_adv, w_val = bf(torch.randn(A, 512, generator=g) * 0.1).to(DEV), bf(torch.randn(1, 512, generator=g) * 0.1).to(DEV)
+    for step in range(2):                                           # both parities of the max-weight slot
+        H.sumtree_sample(tree, lay, st, 11, idx, p, begin_n_items=n_items, is_n_scale=1.0)
+        dq1, pr1 = torch.full((B, A), 9.0, device=DEV), torch.zeros(B, device=DEV)
+        dh1 = torch.full((B, 1024), 9.0, dtype=torch.bfloat16, device=DEV)
+        H.apex_td_dh(q_on, q_tg, idx, act, rew, done, p, st, 0.97, 0.6, 1e-5, dq1, pr1, hq, w_adv, w_val, dh1)
+        s1 = H.read_step_state(st)
+        dq0, pr0 = torch.zeros(B, A, device=DEV), torch.zeros(B, device=DEV)
+        H.apex_td(q_on, q_tg, idx, act, rew, done, p, st, 0.97, 0.6, 1e-5, dq0, pr0)
+        s0 = H.read_step_state(st)
+        dh0 = torch.zeros(B, 1024, dtype=torch.bfloat16, device=DEV)
+        z = [torch.zeros(A, 512, device=DEV), torch.zeros(A, device=DEV), torch.zeros(1, 512, device=DEV), torch.zeros(1, device=DEV)]
+        H.head_bwd(dq0, hq, w_adv, w_val, dh0, *z, parts=1)
+        assert s1["max_w"] == pytest.approx(s0["max_w"], rel=1e-5) and s1["loss"] == pytest.approx(s0["loss"], rel=1e-4)
+        torch.testing.assert_close(dq1, dq0, rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(pr1, pr0, rtol=1e-6, atol=0)
+        torch.testing.assert_close(dh1.float(), dh0.float(), rtol=2e-2, atol=1e-7)
+        H.step_end(st)
+
+
 @pytest.mark.parametrize("done_offset", [0, 5])
 def test_r2d2_td(hip, done_offset):
     H = hip
