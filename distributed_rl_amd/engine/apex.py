@@ -114,8 +114,9 @@ class ApexEngine:
         """Sharded PER: rank r draws its batch from its own shard, so item i is drawn with probability
         p_i / (world * Σp_local) and its single-tree-equivalent IS weight is (N_global * p_i / (world * Σp_local))^-β.
         The TD kernel computes (n_scale * N_local * p_i / Σp_local)^-β, hence n_scale = N_global / (world * N_local)
-        (= 1 for equally filled shards). One tiny all-reduce, called at capture time (the value is baked into the graph)
-        and by the learner whenever the fill level changed materially."""
+        (= 1 for equally filled shards). One tiny all-reduce, called at capture time: the value is baked into the graph.
+        Every rank must call it at the same point (it is a collective); shards fed by equally many actors fill at the
+        same rate, so the ratio stays ~1 after that."""
         if self.dist is None or not self.dist.enabled:
             self.n_scale = 1.0
             return 1.0

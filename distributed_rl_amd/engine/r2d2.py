@@ -161,7 +161,16 @@ class R2D2Engine:
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
-        self.fwd_chunks = max(1, int(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks)))
+        # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
+        fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
+        if "," in fc:
+            cuts = sorted(set(int(x) for x in fc.split(",") if 0 < int(x) < self.T))
+        else:
+            n_ = max(1, int(fc))
+            csz_ = (self.T + n_ - 1) // n_
+            cuts = list(range(csz_, self.T, csz_))
+        self.fwd_bounds = list(zip([0] + cuts, cuts + [self.T]))
+        self.fwd_chunks = len(self.fwd_bounds)
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
@@ -198,9 +207,7 @@ class R2D2Engine:
             # kernel - W_hh slice back into LDS - and the recurrence steps slow down under the torso's memory traffic)
             H.gather_state(r.h0, r.idx, None, self.tg.hs[0])
             H.gather_state(r.c0, r.idx, self.tg.cs[0], None)
-            csz = (T + self.fwd_chunks - 1) // self.fwd_chunks
-            for t0 in range(0, T, csz):
-                st_ = (t0, min(T, t0 + csz))
+            for st_ in self.fwd_bounds:
                 seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_)
                 with fj.fork(0):
                     seq_recurrence(T, B, Hd, self.Pb, self.on, self.persistent_lstm, steps=st_)
