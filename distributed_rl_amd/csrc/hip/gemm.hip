@@ -734,6 +734,14 @@ typedef ConvOp<84, 84, 4, 8, 4, true, true> Conv1OffOp;
 typedef ConvOp<20, 20, 32, 4, 2, false> Conv2Op;
 typedef ConvOp<9, 9, 64, 3, 1, false> Conv3Op;
 
+__device__ __forceinline__ Epilogue make_epi_dev(void* C, long long ldc, float scale, int flags) {
+    Epilogue e;
+    e.C = C; e.ldc = ldc; e.bias = nullptr; e.mask = nullptr; e.ldmask = 0; e.scale = scale; e.flags = flags;
+    e.xg = nullptr; e.ldxg = 0; e.c_prev = nullptr; e.c_out = nullptr; e.h_out = nullptr; e.gates_out = nullptr;
+    e.rm_hc = e.rm_wc = e.rm_s = e.rm_h = e.rm_w = 1; e.rm_py = e.rm_px = 0;
+    return e;
+}
+
 static Epilogue make_epi(void* C, long long ldc, const float* bias, const void* mask, long long ldmask, float scale, int flags) {
     Epilogue e;
     e.C = C; e.ldc = ldc; e.bias = bias; e.mask = (const bf16_t*)mask; e.ldmask = ldmask; e.scale = scale; e.flags = flags;
@@ -1155,4 +1163,134 @@ DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, i
 #undef CB2
 #undef CB3
     return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One BPTT step of the LSTM in ONE launch (was: pointwise kernel + split-K GEMM, ~10 us per step of pure latency).
+// ---------------------------------------------------------------------------------------------------
+// dh_rec_{t-1}[m][h] = sum_n dG_t[m][n] * W_hh[n][h]  with  dG_t = pointwise(dh_head_t + dh_rec_t, dc_t, gates_t, c_t, c_{t-1}).
+// grid = (H/64 output tiles j, H/64 K-slices z). Workgroup (j, z) recomputes the pointwise part for the 64 units of
+// slice z (all 8 workgroups of a slice do the same cheap work: nobody has to wait for anybody inside the launch),
+// writes the bf16 dG tile [64][256] straight into LDS in the A-operand layout, multiplies it with W_hh[256 z .., 64 j ..]
+// (prefetched into registers before the pointwise phase) and adds its 64 x 64 partial sum into dh_rec_out through the
+// LDS-staged 256-byte atomics of gemm_epilogue. The j == 0 workgroups also store dG (weight-gradient GEMMs later) and
+// the new dc. Three rotating dh_rec buffers (read / accumulate / being zeroed) and two dc buffers make the launch free
+// of any intra-launch ordering.
+__global__ __launch_bounds__(NTHREADS) void k_lstm_bwd_step(const bf16_t* __restrict__ dh_head, const float* __restrict__ dh_rec_in,
+                                                           float* __restrict__ dh_rec_out, float* __restrict__ dh_rec_zero,
+                                                           const float* __restrict__ dc_in, float* __restrict__ dc_out,
+                                                           const bf16_t* __restrict__ gates, const float* __restrict__ c_t,
+                                                           const float* __restrict__ c_prev, bf16_t* __restrict__ dgates,
+                                                           DenseOp w_hh, int M) {
+    constexpr int HD = 512, UN = 64, KW = 4 * UN;              // units per slice, gate columns per slice
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* As = smem;                                         // [64][256] bf16, nrm layout (4 sub-tiles of 64 k)
+    uint8_t* Bs = smem + 64 * KW * 2;                           // 4 TR tiles [64 k][64 n] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int j = blockIdx.x, z = blockIdx.y;
+    // W_hh tile loads first: they land while the pointwise phase runs
+    RowCache<64, true, 64, DenseOp> rb;
+    rb.init(w_hh, 64 * j, tid);
+    Stage<64, true, 64, DenseOp> sb[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) sb[kt].load(w_hh, rb, 64 * j, KW * z + 64 * kt, 4 * HD, tid, true);
+    // zero this workgroup's 2 KB piece of the buffer the NEXT step accumulates into
+    {
+        float* zp = dh_rec_zero + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 512;
+        if ((blockIdx.y * gridDim.x + blockIdx.x) * 512 < M * HD)
+            *reinterpret_cast<float2*>(zp + 2 * tid) = make_float2(0.f, 0.f);
+    }
+    // pointwise: thread = 4 consecutive units x 4 rows, every load 16 bytes wide and ALL of them issued before the first
+    // use (one memory round trip for the whole phase: the launch is latency-bound, not bandwidth-bound)
+    const int u4 = (tid & 15) * 4, ug = UN * z + u4;
+    float4 v_rec[4], v_dc[4], v_ct[4], v_cp[4];
+    uint4 v_g[4][2];
+    uint2 v_dh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min((tid >> 4) + 16 * i, M - 1);           // rows >= M read row M-1 (results dropped below)
+        const size_t e = (size_t)m * HD + ug;
+        v_rec[i] = *reinterpret_cast<const float4*>(dh_rec_in + e);
+        v_dc[i] = *reinterpret_cast<const float4*>(dc_in + e);
+        v_ct[i] = *reinterpret_cast<const float4*>(c_t + e);
+        v_cp[i] = *reinterpret_cast<const float4*>(c_prev + e);
+        v_g[i][0] = *reinterpret_cast<const uint4*>(gates + e * 4);
+        v_g[i][1] = *reinterpret_cast<const uint4*>(gates + e * 4 + 8);
+        v_dh[i] = dh_head ? *reinterpret_cast<const uint2*>(dh_head + e) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = (tid >> 4) + 16 * i;
+        const bool live = m < M;
+        const size_t e = (size_t)min(m, M - 1) * HD + ug;
+        const float rec[4] = {v_rec[i].x, v_rec[i].y, v_rec[i].z, v_rec[i].w}, dcv[4] = {v_dc[i].x, v_dc[i].y, v_dc[i].z, v_dc[i].w};
+        const float ct[4] = {v_ct[i].x, v_ct[i].y, v_ct[i].z, v_ct[i].w}, cp[4] = {v_cp[i].x, v_cp[i].y, v_cp[i].z, v_cp[i].w};
+        const uint32_t gw[8] = {v_g[i][0].x, v_g[i][0].y, v_g[i][0].z, v_g[i][0].w, v_g[i][1].x, v_g[i][1].y, v_g[i][1].z, v_g[i][1].w};
+        const float dhh[4] = {__uint_as_float(v_dh[i].x << 16), __uint_as_float(v_dh[i].x & 0xffff0000u),
+                              __uint_as_float(v_dh[i].y << 16), __uint_as_float(v_dh[i].y & 0xffff0000u)};
+        uint32_t o[8];
+        float dcn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dh = rec[q] + dhh[q];
+            const float ig = __uint_as_float(gw[2 * q] << 16), fg = __uint_as_float(gw[2 * q] & 0xffff0000u);
+            const float gg = __uint_as_float(gw[2 * q + 1] << 16), og = __uint_as_float(gw[2 * q + 1] & 0xffff0000u);
+            const float tc = 2.0f / (1.0f + __expf(-2.0f * ct[q])) - 1.0f;
+            const float dcell = dh * og * (1.0f - tc * tc) + dcv[q];
+            const float d_o = dh * tc * og * (1.0f - og);
+            const float d_i = dcell * gg * ig * (1.0f - ig);
+            const float d_g = dcell * ig * (1.0f - gg * gg);
+            const float d_f = dcell * cp[q] * fg * (1.0f - fg);
+            o[2 * q] = live ? pack_bf2(d_i, d_f) : 0u;
+            o[2 * q + 1] = live ? pack_bf2(d_g, d_o) : 0u;
+            dcn[q] = dcell * fg;
+        }
+        if (j == 0 && live) {
+            *reinterpret_cast<float4*>(dc_out + e) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+            *reinterpret_cast<uint4*>(dgates + e * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(dgates + e * 4 + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+        // A tile: row m, local gate columns 4 u4 .. 4 u4 + 15 = the two 16-B chunks u4/2, u4/2 + 1
+        *reinterpret_cast<uint4*>(As + nrm_off<64>(m, u4 >> 1)) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(As + nrm_off<64>(m, (u4 >> 1) + 1)) = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) sb[kt].store(Bs + kt * 8192, tid);
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KW / 32; ++ks) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = read_frag<64, false>(As, wm * 32 + a * 16, ks, lane);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = read_frag<64, true>(Bs + (ks >> 1) * 8192, wn * 32 + b * 16, ks & 1, lane);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, bf[b]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, af[a]), acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    const Epilogue ep = make_epi_dev(dh_rec_out, HD, 1.0f, EPI_OUT_F32 | EPI_ATOMIC);
+    gemm_epilogue<64, 64, 2, 2>(acc, ep, 0, 64 * j, M, HD, smem, tid, lane, wm, wn);
+}
+
+// dh_head bf16 [M][H] (or null), dh_rec_* f32 [M][H] (three distinct buffers), dc_* f32 [M][H] (two distinct buffers),
+// gates bf16 [M][4H] (post-activation, interleaved), c_t / c_prev f32 [M][H], dgates bf16 [M][4H], w_hh bf16 [4H][H].
+DRL_API int drl_lstm_bwd_step(const void* dh_head, const float* dh_rec_in, float* dh_rec_out, float* dh_rec_zero,
+                              const float* dc_in, float* dc_out, const void* gates, const float* c_t, const float* c_prev,
+                              void* dgates, const void* w_hh, int M, int H, hipStream_t s) {
+    if (H != 512 || M <= 0 || M > 64) return -1;
+    if (dh_rec_in == dh_rec_out || dh_rec_out == dh_rec_zero || dh_rec_in == dh_rec_zero || dc_in == dc_out) return -2;
+    DenseOp W{(const bf16_t*)w_hh, H, 4 * H};
+    constexpr int LDS = 64 * 256 * 2 + 4 * 8192;
+    k_lstm_bwd_step<<<dim3(H / 64, H / 64), NTHREADS, LDS, s>>>((const bf16_t*)dh_head, dh_rec_in, dh_rec_out, dh_rec_zero, dc_in,
+                                                                dc_out, (const bf16_t*)gates, c_t, c_prev, (bf16_t*)dgates, W, M);
+    return (int)hipGetLastError();
 }

@@ -152,6 +152,8 @@ class R2D2Engine:
         self.dG = torch.zeros(L, B, 4 * Hd, **bf)
         self.dh_rec = torch.zeros(B, Hd, device=dev)
         self.dc = torch.zeros(B, Hd, device=dev)
+        self.dh_rec3 = torch.zeros(3, B, Hd, device=dev)     # fused BPTT step: read / accumulate / being-zeroed rotation
+        self.dc2 = torch.zeros(2, B, Hd, device=dev)
         self.d3 = torch.zeros(NB * 49, 64, **bf)
         self.dcol3 = torch.zeros(NB * 49, 576, **bf)
         self.d2 = torch.zeros(NB * 81, 64, **bf)
@@ -161,6 +163,7 @@ class R2D2Engine:
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
+        self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
         fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
         if "," in fc:
@@ -246,16 +249,28 @@ class R2D2Engine:
         # heavy kernels slow the chain down by as much as they gain (4.13 / 4.16 / 4.36 / 4.81 ms per step for 1 / 3 /
         # 5 / 8 chunks), so the default is ONE chunk: the torso backward on a side stream next to the LSTM
         # weight-gradient GEMMs, after the chain.
-        self.dh_rec.zero_()
-        self.dc.zero_()
         w_hh = Pb.view("lstm.w_hh")
         csz = (L + self.bwd_chunks - 1) // self.bwd_chunks
         starts = set(range(0, L, csz))
-        for t in range(T - 1, burn - 1, -1):
+        fused_step = self.fused_bptt
+        if fused_step:
+            R, DC = self.dh_rec3, self.dc2
+            R.zero_()
+            DC[0].zero_()
+        else:
+            self.dh_rec.zero_()
+            self.dc.zero_()
+        for s_, t in enumerate(range(T - 1, burn - 1, -1)):
             k = t - burn
-            H.lstm_bwd_point(self.dhs[k], self.dh_rec, self.dc, on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k])
-            if t > burn:
-                H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
+            if fused_step and t > burn:                             # pointwise + recurrent GEMM of the step: ONE launch
+                H.lstm_bwd_step(self.dhs[k], R[s_ % 3], R[(s_ + 1) % 3], R[(s_ + 2) % 3], DC[s_ % 2], DC[(s_ + 1) % 2],
+                                on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k], w_hh)
+            elif fused_step:                                        # last step: nothing recurrent left to compute
+                H.lstm_bwd_point(self.dhs[k], R[s_ % 3], DC[s_ % 2], on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k])
+            else:
+                H.lstm_bwd_point(self.dhs[k], self.dh_rec, self.dc, on.gates[t], on.cs[t + 1], on.cs[t], self.dG[k])
+                if t > burn:
+                    H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
             if k in starts:
                 with fj.fork(1):
                     self._torso_backward(k, min(L, k + csz))

@@ -42,6 +42,7 @@ SIGS = {
     "drl_lstm_seq_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P],
     # lstm.hip
     "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
+    "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "drl_seq_offsets": [P, I, I, L, P, P],
     "drl_gather_state": [P, P, I, I, P, P, P],
     "drl_add2": [P, P, P, I, P],

@@ -438,6 +438,22 @@ def lstm_bwd_point(dh_head, dh_rec, dc, gates, c_t, c_prev, dgates) -> None:
         "lstm_bwd_point")
 
 
+def lstm_bwd_step_supported(B: int, Hd: int) -> bool:
+    return Hd == 512 and 0 < B <= 64
+
+
+def lstm_bwd_step(dh_head, dh_rec_in, dh_rec_out, dh_rec_zero, dc_in, dc_out, gates, c_t, c_prev, dgates, w_hh) -> None:
+    """One BPTT step in ONE launch (gemm.hip k_lstm_bwd_step): dgates = pointwise(dh_head + dh_rec_in, dc_in, ...),
+    dc_out, and dh_rec_out += dgates @ w_hh. dh_rec_out must be zero on entry; dh_rec_zero (a third buffer) is zeroed for
+    the step after; the three dh_rec buffers and the two dc buffers must be distinct."""
+    B, Hd = c_t.shape
+    for t, n in ((dh_rec_in, "dh_rec_in"), (dh_rec_out, "dh_rec_out"), (dh_rec_zero, "dh_rec_zero"), (dc_in, "dc_in"), (dc_out, "dc_out")):
+        _chk(t, torch.float32, n)
+    _chk(gates, torch.bfloat16, "gates"); _chk(dgates, torch.bfloat16, "dgates"); _chk(w_hh, torch.bfloat16, "w_hh")
+    _ck(native.hip().drl_lstm_bwd_step(_p(dh_head), _p(dh_rec_in), _p(dh_rec_out), _p(dh_rec_zero), _p(dc_in), _p(dc_out),
+                                       _p(gates), _p(c_t), _p(c_prev), _p(dgates), _p(w_hh), B, Hd, _s()), "lstm_bwd_step")
+
+
 def seq_offsets(idx, T: int, frame_bytes: int, off) -> None:
     _chk(idx, torch.int32, "idx"); _chk(off, torch.int64, "off")
     assert off.numel() >= idx.numel() * T

@@ -186,11 +186,33 @@ def main():
     cases["lstm_seq_1net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts)], Ts, 64, 512, sync, err), 2 * 64 * 2048 * 512 * Ts, 0)
     cases["lstm_seq_2net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts), (xgs, whh, hss2, css2, None)], Ts, 64, 512, sync, err),
                               2 * 2 * 64 * 2048 * 512 * Ts, 0)
+    # BPTT: 80 steps as the engine issues them - two launches per step vs the fused one-launch step
+    Tb = 80
+    dhs_b = bf(Tb, 64, 512, scale=0.05)
+    gts_b = (torch.rand(Tb, 64, 2048, device=DEV) * 0.9 + 0.05).to(torch.bfloat16)
+    css_b = torch.randn(Tb + 1, 64, 512, device=DEV) * 0.5
+    dG_b = torch.zeros(Tb, 64, 2048, dtype=torch.bfloat16, device=DEV)
+    rec1, dc1 = torch.zeros(64, 512, device=DEV), torch.zeros(64, 512, device=DEV)
+    R3, DC2 = torch.zeros(3, 64, 512, device=DEV), torch.zeros(2, 64, 512, device=DEV)
+
+    def bptt_two():
+        for s_ in range(Tb):
+            t = Tb - 1 - s_
+            H.lstm_bwd_point(dhs_b[t], rec1, dc1, gts_b[t], css_b[t + 1], css_b[t], dG_b[t])
+            H.gemm(H.NN, dG_b[t], whh, rec1, 64, 512, 2048, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
+
+    def bptt_fused():
+        for s_ in range(Tb):
+            t = Tb - 1 - s_
+            H.lstm_bwd_step(dhs_b[t], R3[s_ % 3], R3[(s_ + 1) % 3], R3[(s_ + 2) % 3], DC2[s_ % 2], DC2[(s_ + 1) % 2], gts_b[t],
+                            css_b[t + 1], css_b[t], dG_b[t], whh)
+    cases["lstm_bptt80_two_launches"] = (bptt_two, 2 * 64 * 2048 * 512 * Tb, 0)
+    cases["lstm_bptt80_fused_step"] = (bptt_fused, 2 * 64 * 2048 * 512 * Tb, 0)
     print("%-18s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
     for name, (fn, flops, byts) in cases.items():
         if args.only and not any(o in name for o in args.only.split(",")):
             continue
-        us = timeit(fn, 3 if name.startswith("lstm_1") or name.startswith("lstm_seq") else args.reps)
+        us = timeit(fn, 3 if name.startswith("lstm_1") or name.startswith("lstm_seq") or name.startswith("lstm_bptt") else args.reps)
         print("%-18s %10.1f %10.1f %10.1f" % (name, us, flops / us / 1e6, byts / us / 1e3))
 
 

@@ -679,3 +679,34 @@ def test_lstm_step_and_persistent_sequence(hip, M):
     # both kernels see identical bf16 operands: they agree far tighter than either agrees with fp32
     torch.testing.assert_close(outs[1][0], outs[0][0], rtol=2e-2, atol=1e-2)
     torch.testing.assert_close(outs[1][2], outs[0][2], rtol=2e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M", [8, 16, 64])
+def test_lstm_bwd_step_fused_matches_two_launches(hip, M):
+    """One-launch BPTT step (pointwise + recurrent GEMM, rotating buffers) against lstm_bwd_point + split-K GEMM over
+    several consecutive steps."""
+    H = hip
+    Hd, steps = 512, 4
+    g = torch.Generator().manual_seed(M)
+    w_hh = bf(torch.randn(4 * Hd, Hd, generator=g) * 0.05).to(DEV)
+    gates = bf(torch.rand(steps, M, 4 * Hd, generator=g) * 0.9 + 0.05).to(DEV)
+    cs = (torch.randn(steps + 1, M, Hd, generator=g) * 0.5).to(DEV)
+    dhs = bf(torch.randn(steps, M, Hd, generator=g) * 0.1).to(DEV)
+    # reference: two launches per step, in-place buffers
+    dh_rec, dc = torch.zeros(M, Hd, device=DEV), torch.zeros(M, Hd, device=DEV)
+    dG0 = torch.zeros(steps, M, 4 * Hd, dtype=torch.bfloat16, device=DEV)
+    for s_ in range(steps):
+        t = steps - 1 - s_
+        H.lstm_bwd_point(dhs[t], dh_rec, dc, gates[t], cs[t + 1], cs[t], dG0[t])
+        H.gemm(H.NN, dG0[t], w_hh, dh_rec, M, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
+    # fused
+    R, DC = torch.zeros(3, M, Hd, device=DEV), torch.zeros(2, M, Hd, device=DEV)
+    R[2].fill_(7.0)                                                 # must be zeroed by the first step
+    dG1 = torch.zeros_like(dG0)
+    for s_ in range(steps):
+        t = steps - 1 - s_
+        H.lstm_bwd_step(dhs[t], R[s_ % 3], R[(s_ + 1) % 3], R[(s_ + 2) % 3], DC[s_ % 2], DC[(s_ + 1) % 2], gates[t], cs[t + 1],
+                        cs[t], dG1[t], w_hh)
+    torch.testing.assert_close(dG1.float(), dG0.float(), rtol=2e-2, atol=1e-5)
+    torch.testing.assert_close(R[steps % 3], dh_rec, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(DC[steps % 2], dc, rtol=2e-3, atol=1e-4)          # fed by dh_rec: float-atomics order
