@@ -32,6 +32,9 @@ struct LstmSeqNet {
     int* sync;            // arrival counter of this network (zeroed by the host wrapper before the launch)
 };
 
+#ifndef DRL_LSTM_B128_LOADS
+#define DRL_LSTM_B128_LOADS 1
+#endif
 #define SPIN_LIMIT (1 << 17)
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned long long u64_t;
@@ -81,6 +84,9 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet 
         const float4 c0 = *reinterpret_cast<const float4*>(a.cs + (size_t)m * HD + u0);
         c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
     }
+#if DRL_LSTM_B128_LOADS
+    const auto hs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hs, 0, (int)((size_t)(T + 1) * M * HD * sizeof(bf16_t)), 0x00020000);
+#endif
     __shared__ int s_dead;
     if (tid == 0) s_dead = 0;
     __syncthreads();
@@ -91,13 +97,24 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet 
 #pragma unroll
         for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const float4*>(xrow + 4 * q);
         if (t > 0) grid_wait(a.sync, NWG * t, err, &s_dead);
-        u64_t* hrow = reinterpret_cast<u64_t*>(a.hs + ((size_t)t * M + m) * HD + g4 * 8);
         bf16x8 hf[NKS];
+#if DRL_LSTM_B128_LOADS
+        // ONE 16-byte sc1 buffer load per fragment (aux 16 = sc1: served by L2 / memory, never by this CU's L1)
+        const unsigned hoff = (unsigned)((((size_t)t * M + m) * HD + g4 * 8) * sizeof(bf16_t));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hs_rsrc, hoff + ks * 64, 0, 16);
+            hf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+#else
+        u64_t* hrow = reinterpret_cast<u64_t*>(a.hs + ((size_t)t * M + m) * HD + g4 * 8);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {                        // 2 x global_load_dwordx2 sc1 per fragment
             const u64_t lo = __hip_atomic_load(hrow + ks * 8, RLX_AGENT), hi = __hip_atomic_load(hrow + ks * 8 + 1, RLX_AGENT);
             hf[ks] = __builtin_bit_cast(bf16x8, make_ulonglong2(lo, hi));
         }
+#endif
         f32x4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -163,6 +163,7 @@ class R2D2Engine:
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
+        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "0") != "0"    # measured equal (3.26-3.30 ms either way)
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
         fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
@@ -210,16 +211,28 @@ class R2D2Engine:
             # kernel - W_hh slice back into LDS - and the recurrence steps slow down under the torso's memory traffic)
             H.gather_state(r.h0, r.idx, None, self.tg.hs[0])
             H.gather_state(r.c0, r.idx, self.tg.cs[0], None)
+            dual = self.persistent_lstm and self.dual_lstm
             for st_ in self.fwd_bounds:
                 seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_)
-                with fj.fork(0):
-                    seq_recurrence(T, B, Hd, self.Pb, self.on, self.persistent_lstm, steps=st_)
+                if not dual:
+                    with fj.fork(0):
+                        seq_recurrence(T, B, Hd, self.Pb, self.on, self.persistent_lstm, steps=st_)
                 seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_)
-                with fj.fork(2):
-                    seq_recurrence(T, B, Hd, self.Tb, self.tg, self.persistent_lstm, steps=st_)
+                if dual:
+                    # both recurrences of the chunk in ONE persistent launch (64 workgroups): 685 us for 120 steps of two
+                    # nets against 655 us for one, so the second network rides along almost for free
+                    t0, t1 = st_
+                    with fj.fork(0):
+                        H.lstm_seq_fwd([(self.on.xg[t0:t1], self.Pb.view("lstm.w_hh"), self.on.hs[t0:t1 + 1], self.on.cs[t0:t1 + 1],
+                                         self.on.gates[t0:t1]),
+                                        (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1],
+                                         None)], t1 - t0, B, Hd, self.on.sync, self.on.err)
+                else:
+                    with fj.fork(2):
+                        seq_recurrence(T, B, Hd, self.Tb, self.tg, self.persistent_lstm, steps=st_)
             with fj.fork(0):
                 seq_heads(T, B, Hd, self.Pb, self.P, self.on)
-            with fj.fork(2):
+            with fj.fork(2 if not dual else 0):
                 seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
         else:
             seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on)
