@@ -989,6 +989,8 @@ struct TreeExtra {        // host-side description (ctypes mirror: ops/hip.py Tr
     void* st_end;
 };
 
+static_assert(sizeof(TreeExtra) == 120, "TreeExtra is mirrored field by field by ops/hip.py (ctypes)");
+
 struct TreeBody {
     struct Args { TreeDesc tr; const int* idx; const float* val; int n, kind, n2_blocks; const int* gen; const int* gen_expected; StepState* st_end; };
     static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
