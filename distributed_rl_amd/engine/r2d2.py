@@ -114,7 +114,7 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
 class R2D2Engine:
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 1, fwd_chunks: int = 2):
+                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks: int = 2):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = dev = torch.device(device)
         self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
@@ -256,12 +256,11 @@ class R2D2Engine:
             H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
         H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
-        # BPTT: a latency-bound chain of 2 small launches per step. Everything below the LSTM is row-wise independent
-        # (weight gradients accumulate with atomics), so the window is cut into time chunks and the torso backward of a
-        # chunk can run on a side stream as soon as the chain has passed it (bwd_chunks > 1). Measured on MI355X the
-        # heavy kernels slow the chain down by as much as they gain (4.13 / 4.16 / 4.36 / 4.81 ms per step for 1 / 3 /
-        # 5 / 8 chunks), so the default is ONE chunk: the torso backward on a side stream next to the LSTM
-        # weight-gradient GEMMs, after the chain.
+        # BPTT: a latency-bound chain of one small launch per step (64 workgroups) that leaves 3/4 of the chip idle.
+        # Everything below the LSTM is row-wise independent (weight gradients accumulate with atomics), so the window is
+        # cut into time chunks and the torso backward of a chunk runs on a side stream as soon as the chain has passed
+        # it. The heavy kernels slow the chain down, so few chunks are best: 3.26 / 3.12 / 3.13 / 3.18 / 3.38 ms per step
+        # for 1 / 2 / 3 / 4 / 8 chunks (with the two-launch chain of earlier versions chunking did not pay at all).
         w_hh = Pb.view("lstm.w_hh")
         csz = (L + self.bwd_chunks - 1) // self.bwd_chunks
         starts = set(range(0, L, csz))
