@@ -85,6 +85,7 @@ struct DenseOp {
     __device__ __forceinline__ off_t addr(off_t rb, int c) const { return rb + (off_t)c; }
     __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
     static constexpr bool HAS_CLASS = false;
+    static constexpr bool ROW_PREFETCH = false;
     typedef uint4 raw_t;     // 8 bf16
     __device__ __forceinline__ raw_t load_raw(off_t off) const { return *reinterpret_cast<const uint4*>(p + off); }
     __device__ __forceinline__ const void* gptr(off_t off) const { return p + off; }
@@ -114,6 +115,21 @@ struct ConvOp {
         if constexpr (OFF_) fb = frame_off[b];
         else fb = (off_t)b * (off_t)(H * W * C);
         return fb + (off_t)(((oy * S) * W + ox * S) * C);
+    }
+    // OFF_: the frame base is a dependent global load (frame_off[b]). When the rows of a tile change every K-tile (TR
+    // operand of the weight-gradient GEMM) that load would sit in front of every data load and serialise the prefetch
+    // ring, so the mainloop fetches the frame bases of a stage's NEXT tile right after issuing its current one
+    // (Stage::load) and hands them back here.
+    static constexpr bool ROW_PREFETCH = OFF_;
+    __device__ __forceinline__ long long row_pref(int m) const {
+        if constexpr (OFF_) return frame_off[(m < rows ? m : 0) / (OH * OW)];
+        else return 0;
+    }
+    __device__ __forceinline__ off_t row_base_fb(int m, long long fb) const {
+        const int mm = m < rows ? m : 0;
+        const int b = mm / (OH * OW), rem = mm - b * (OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        return (off_t)fb + (off_t)(((oy * S) * W + ox * S) * C);
     }
     __device__ __forceinline__ int col_off(int kc) const {
         int kh = kc / KWC;
@@ -174,6 +190,7 @@ struct DgradOp {          // A operand (normal orientation): rows = pixels of on
     static constexpr int K = TS * TS * CO_;
     static_assert(KS_ % S_ == 0 && H_ % S_ == 0 && W_ % S_ == 0, "parity classes must tile the input");
     static constexpr bool HAS_CLASS = true;
+    static constexpr bool ROW_PREFETCH = false;
     const bf16_t* p;      // dY [frames][OH][OW][CO]
     int rows;             // frames*HC*WC (per class)
     int py, px;           // set from blockIdx.z in the kernel
@@ -208,6 +225,7 @@ template <int KS_, int S_, int CI_, int CO_>
 struct WdgradOp {         // B operand (transposed orientation, memory rows = k): W[co][ky][kx][ci], k = (ty, tx, co)
     static constexpr int TS = KS_ / S_, K = TS * TS * CO_;
     static constexpr bool HAS_CLASS = true;
+    static constexpr bool ROW_PREFETCH = false;
     const bf16_t* p;
     int py, px;
     __device__ __forceinline__ void set_class(int z) { py = z / S_; px = z % S_; }
@@ -273,13 +291,23 @@ struct Stage {
     static_assert(NCH >= 1 && (ROWS * CPR) % NTHREADS == 0, "tile too small for 256 threads");
     typename Op::raw_t reg[NCH];
     unsigned valid;
+    static constexpr bool PRE = TR && Op::ROW_PREFETCH;
+    long long pre[PRE ? NCH : 1];          // frame bases of the rows of the NEXT tile this stage will load (PRE only)
+    __device__ __forceinline__ void prefetch(const Op& op, int k0, int tid) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) pre[i] = op.row_pref(k0 + (tid + i * NTHREADS) / CPR);
+        }
+    }
     // out0 = first out index of the tile, k0 = first contraction index, Kc = contraction length. BRANCH-FREE on
     // purpose: out-of-range rows / k (and whole inactive tiles past the end of the K range) read element 0 of the
     // operand and are zeroed when the tile is written to LDS. With no control flow around the loads hipcc keeps
     // counted s_waitcnt vmcnt(N) and the register ring really stays in flight (conditional loads made it fall back
     // to vmcnt(0) everywhere).
+    // next_k0 (PRE only): first contraction index of the tile this stage loads NEXT time; its frame bases are fetched
+    // right behind this tile's data loads, a whole ring revolution before they are needed.
     __device__ __forceinline__ void load(const Op& op, const RowCache<OUT, TR, BKT, Op>& rc, int out0, int k0, int Kc, int tid,
-                                         bool active) {
+                                         bool active, int next_k0 = 0) {
         valid = 0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -287,7 +315,8 @@ struct Stage {
             const int kidx = TR ? k0 + r : k0 + c * 8;
             typename Op::off_t rb;
             bool ok = active && kidx < Kc;
-            if constexpr (TR) { rb = op.row_base(kidx); ok = ok && op.row_ok(kidx); }
+            if constexpr (PRE) { rb = op.row_base_fb(kidx, pre[i]); ok = ok && op.row_ok(kidx); }
+            else if constexpr (TR) { rb = op.row_base(kidx); ok = ok && op.row_ok(kidx); }
             else { rb = rc.base[i]; ok = ok && ((rc.ok >> i) & 1u) && op.pair_ok(rb, kidx); }
             typename Op::off_t off;
             if constexpr (TR) off = ok ? rb + (typename Op::off_t)op.col_off(out0 + c * 8) : 0;
@@ -295,6 +324,7 @@ struct Stage {
             reg[i] = op.load_raw(off);
             valid |= (ok ? 1u : 0u) << i;
         }
+        prefetch(op, next_k0, tid);
     }
     __device__ __forceinline__ void store(uint8_t* lds, int tid) const {
 #pragma unroll
@@ -479,8 +509,13 @@ __device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int 
     Stage<BN, B_TR, BKT, BOp> sb[D];
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        sa[s].load(aop, ra, m0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1);
-        sb[s].load(bop, rb, n0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1);
+        sa[s].prefetch(aop, (kt0 + s) * BKT, tid);
+        sb[s].prefetch(bop, (kt0 + s) * BKT, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        sa[s].load(aop, ra, m0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1, (kt0 + s + D) * BKT);
+        sb[s].load(bop, rb, n0, (kt0 + s) * BKT, Kc, tid, kt0 + s < kt1, (kt0 + s + D) * BKT);
     }
     sa[0].store(As(0), tid);
     sb[0].store(Bs(0), tid);
@@ -490,8 +525,8 @@ __device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int 
     // tile cur+1 from its register set into the other LDS buffer, barrier.
     auto substep = [&](auto sc, int cur) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
-        sa[S].load(aop, ra, m0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
-        sb[S].load(bop, rb, n0, (cur + D) * BKT, Kc, tid, cur + D < kt1);
+        sa[S].load(aop, ra, m0, (cur + D) * BKT, Kc, tid, cur + D < kt1, (cur + 2 * D) * BKT);
+        sb[S].load(bop, rb, n0, (cur + D) * BKT, Kc, tid, cur + D < kt1, (cur + 2 * D) * BKT);
         if (STORE_FIRST) {   // tile cur+1 -> the other LDS buffer BEFORE the MFMA phase: its write latency hides under it
             sa[(S + 1) % D].store(As((S + 1) & 1), tid);
             sb[(S + 1) % D].store(Bs((S + 1) & 1), tid);

@@ -168,7 +168,7 @@ class R2D2Engine:
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
         fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
         if "," in fc:
-            cuts = sorted(set(int(x) for x in fc.split(",") if 0 < int(x) < self.T))
+            cuts = sorted(set(int(x) for x in fc.split(",") if x.strip() and 0 < int(x) < self.T))
         else:
             n_ = max(1, int(fc))
             csz_ = (self.T + n_ - 1) // n_
