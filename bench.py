@@ -97,7 +97,8 @@ def main():
     extra = {"apex_updates_per_s": updates_s, "loss": st["loss"], "grad_norm": st["grad_norm"],
              "replay_items_per_gpu": cap, "graph": eng._graphs[0] if eng._graphs else "eager"}
 
-    if not args.no_extra:
+    # side metrics only on one GPU: at N > 1 nothing after the timed region may put the headline line at risk
+    if not args.no_extra and dist.world_size == 1:
         try:
             from distributed_rl_amd.engine.actor import ActorEngine
             act = ActorEngine(args.n_action, args.actor_envs, dev, params=eng)
