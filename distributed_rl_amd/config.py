@@ -119,6 +119,8 @@ class LaunchConf:
     transport: str = "shm"           # shm | redis | inproc  (new key)
     num_envs: int = 1                # envs per actor process (new key)
     learner_gpus: int = 1            # data-parallel learner ranks on this node, one per GPU (new key)
+    param_channel: str = ""          # "" = same as transport | "collective" = torch.distributed broadcast (new key)
+    param_backend: str = "gloo"      # backend of the collective parameter channel: gloo | nccl (= RCCL, one GPU per process)
     run_dir: str = ""                # where shm names / heartbeats / logs live (new key)
     extra: Dict[str, str] = field(default_factory=dict)
 

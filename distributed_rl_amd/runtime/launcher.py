@@ -48,6 +48,14 @@ def build_commands(conf, n_actors: int, server: str, run_id: str, extra_learner:
         if conf.actor_device:
             c += ["-d", conf.actor_device]                                                   # run.sh:27-33
         cmds["learner"] = c + extra_learner
+    if conf.param_channel == "collective":
+        # learner -> actors parameter sync by broadcast (RCCL between GPUs, gloo on CPU) instead of the shm register:
+        # learner = rank 0, actor i = rank i of one process group (environment set per child in main())
+        if n_ranks > 1:
+            raise SystemExit("param_channel=collective needs learner_gpus=1 (the data-parallel learners own the default group)")
+        common = common + ["--param-channel", "collective", "--param-backend", conf.param_backend]
+        if "learner" in cmds:
+            cmds["learner"] = cmds["learner"] + ["--param-channel", "collective", "--param-backend", conf.param_backend]
     if conf.actor:
         for i in range(1, n_actors + 1):                                                     # run.sh:36-42
             cmds["actor_%d" % i] = [python, os.path.join(ROOT, "actor_node.py"), "-n", str(i), "-t", str(n_actors)] + \
@@ -71,6 +79,8 @@ def main(argv=None) -> int:
     args = ap.parse_args(argv)
 
     conf = parse_conf(args.conf)
+    if conf.param_channel == "collective" and args.restart_actors:
+        raise SystemExit("param_channel=collective and --restart-actors exclude each other (a process group cannot re-admit a rank)")
     run_id = args.run_id or conf.run_dir or uuid.uuid4().hex[:8]
     cmds = build_commands(conf, args.num_actors, args.server, run_id, args.learner_args.split(), args.actor_args.split())
     print("redis server:", conf.redis_server or args.server)
@@ -89,8 +99,14 @@ def main(argv=None) -> int:
     procs: Dict[str, subprocess.Popen] = {}
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
 
+    pc_port = str(29900 + (abs(hash(run_id)) % 500))
+
     def spawn(name):
-        procs[name] = subprocess.Popen(cmds[name], env=env, cwd=ROOT)
+        e = env
+        if conf.param_channel == "collective" and name != "visdom":
+            rank = 0 if name == "learner" else int(name.split("_")[1])
+            e = dict(env, DRL_PC_RANK=str(rank), DRL_PC_WORLD=str(1 + args.num_actors), DRL_PC_ADDR="127.0.0.1", DRL_PC_PORT=pc_port)
+        procs[name] = subprocess.Popen(cmds[name], env=e, cwd=ROOT)
 
     def teardown():
         for p in procs.values():

@@ -31,12 +31,39 @@ def _common(parser):
     parser.add_argument('--log-dir', type=str, default='', help='Write JSONL metrics here.')
     parser.add_argument('--quiet', action='store_true')
     parser.add_argument('--device', type=str, default='', help="'' = cuda if available else cpu.")
+    parser.add_argument('--param-channel', type=str, default='', choices=['', 'collective'],
+                        help="collective = parameters reach the actors by torch.distributed broadcast (RCCL / gloo) instead of "
+                             "the transport's register; rank / world / rendezvous come from DRL_PC_RANK / _WORLD / _ADDR / _PORT.")
+    parser.add_argument('--param-backend', type=str, default='gloo', choices=['gloo', 'nccl'],
+                        help="backend of the collective parameter channel (nccl = RCCL: every process on its own GPU).")
 
 
 def shard_run_id(run_id: str, rank: int, world: int) -> str:
     """Data-parallel learners: every learner rank owns its OWN experience ring + parameter register (a replay shard in
     its own HBM fed by its own actors); rank 0 keeps the plain run id so single-learner tools keep working."""
     return run_id if world <= 1 or rank == 0 else "%s_r%d" % (run_id, rank)
+
+
+def _flat_numel(algorithm: str, n_action: int) -> int:
+    """Size of the flat fp32 parameter buffer both sides of a parameter channel agree on (models/packing.py)."""
+    from ..models.packing import ParamPack, apex_layout, r2d2_layout
+    lay = apex_layout(n_action) if algorithm == 'ape_x' else r2d2_layout(n_action)
+    return ParamPack(lay, 'cpu').flat.numel()
+
+
+def _collective_params(args, numel: int, device: torch.device):
+    """Join the parameter process group (learner = rank 0, actor i = rank i) and return the broadcast channel."""
+    import datetime
+    import torch.distributed as td
+    from ..transport.collective_params import CollectiveParams
+    rank, world = int(os.environ["DRL_PC_RANK"]), int(os.environ["DRL_PC_WORLD"])
+    addr, port = os.environ.get("DRL_PC_ADDR", "127.0.0.1"), os.environ.get("DRL_PC_PORT", "29900")
+    if args.param_backend == 'nccl':
+        torch.cuda.set_device(device)
+    td.init_process_group(args.param_backend, init_method="tcp://%s:%s" % (addr, port), rank=rank, world_size=world,
+                          timeout=datetime.timedelta(seconds=float(os.environ.get("DRL_CONNECT_TIMEOUT", "120"))))
+    dev = device if args.param_backend == 'nccl' else torch.device('cpu')
+    return CollectiveParams(numel, src_rank=0, group=None, device=dev)
 
 
 def _device(name: str) -> torch.device:
@@ -84,6 +111,9 @@ def actor_main(argv=None) -> int:
             if _time.time() > t_end:
                 raise
             _time.sleep(0.25)
+    if args.param_channel == 'collective':
+        par.close()
+        par = _collective_params(args, _flat_numel(args.algorithm, env.n_action), device)
     hb = _heartbeat(args, "actor", args.no)
     if args.algorithm == 'ape_x':
         engine = None
@@ -147,6 +177,12 @@ def learner_main(argv=None) -> int:
                            args.quiet or rank > 0)
     exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=True, host=args.redisserver,
                        n_slots=args.ring_slots, slot_bytes=args.ring_slot_mb << 20)
+    register = None
+    if args.param_channel == 'collective':
+        if world > 1:
+            raise SystemExit("--param-channel collective needs a single learner rank")
+        register = par               # stays open (unused): actors attach to both segments of the transport before they switch
+        par = _collective_params(args, _flat_numel(args.algorithm, n_action), device)
     hb_table, hb = None, None
     if args.transport == 'shm':
         from .heartbeat import HeartbeatTable
@@ -193,6 +229,8 @@ def learner_main(argv=None) -> int:
             hb.close()
         exp.close()
         par.close()
+        if register is not None:
+            register.close()
         if hb_table is not None:
             hb_table.close()
     return 0

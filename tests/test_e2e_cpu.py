@@ -115,3 +115,29 @@ def test_run_sh_two_data_parallel_learners(tmp_path, run_id):
     assert "learner exited with 0" in r.stdout, r.stdout[-3000:]
     assert os.path.exists(save / "model_5.pth"), r.stdout[-3000:]
     assert not glob.glob("/dev/shm/drl_%s_*" % run_id)             # both shards' segments cleaned up
+
+
+def test_run_sh_collective_param_channel(tmp_path, run_id):
+    """`param_channel=collective` in the conf: learner and actors form one torch.distributed group (gloo on CPU, RCCL
+    between GPUs) and the flat parameter buffer reaches the actors by broadcast instead of the shm register; experience
+    still flows through the shm ring."""
+    conf = tmp_path / "pc.conf"
+    conf.write_text("actor=true\nlearner=true\nvisdom=false\nalgorithm=ape_x\nredis_server=localhost\n"
+                    "visdom_server=localhost\nactor_device=cpu\nparam_channel=collective\nparam_backend=gloo\n")
+    save, logs = tmp_path / "models", tmp_path / "logs"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DRL_NUM_ENVS="2")
+    cmd = [os.path.join(ROOT, "run.sh"), "2", str(conf), "", "--run-id", run_id, "--timeout", "280",
+           "--learner-args", "--max-steps 8 --batch-size 16 --start-memory-size 32 --save-timing 5 --save-dir %s --quiet --device cpu --engine torch" % save,
+           "--actor-args", "--quiet --device cpu --actor-batch 16 --param-period 4 --log-dir %s" % logs]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=330)
+    assert "learner exited with 0" in r.stdout, r.stdout[-3000:]
+    assert os.path.exists(save / "model_5.pth"), r.stdout[-3000:]
+    assert not glob.glob("/dev/shm/drl_%s_*" % run_id)
+    import json
+    versions = []
+    for f in glob.glob(str(logs / "*.jsonl")):
+        for line in open(f):
+            rec = json.loads(line)
+            if rec["name"].startswith("Params version"):
+                versions.append(rec["y"])
+    assert versions and max(versions) >= 1, (versions, r.stdout[-2000:])      # the broadcast reached the actors
