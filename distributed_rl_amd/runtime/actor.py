@@ -111,7 +111,8 @@ class Actor:
         if got is None:
             return False
         self._version, flat = got
-        self.metrics.scalar("Params version %s" % self.name, self.env_steps, self._version)
+        if self.metrics is not None:
+            self.metrics.scalar("Params version %s" % self.name, self.env_steps, self._version)
         if self.engine is not None:
             self.engine.load_flat(flat)
             return True
