@@ -163,6 +163,7 @@ class R2D2Engine:
         import os as _os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
+        H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "0") != "0"    # measured equal (3.26-3.30 ms either way)
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)

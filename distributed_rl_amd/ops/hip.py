@@ -378,8 +378,26 @@ LIB_GEMM = os.environ.get("DRL_LIB_GEMM", "1") != "0"
 LIB_GEMM_MIN_FLOP = float(os.environ.get("DRL_LIB_GEMM_MIN_FLOP", "2.0e10"))
 
 
+_LIB_GEMM_PROBED = None
+
+
+def _lib_gemm_available() -> bool:
+    """torch.mm(bf16, bf16, out_dtype=float32, out=...) exists in this PyTorch build and runs on this device? Probed once;
+    a build without it simply keeps every GEMM on gemm.hip."""
+    global _LIB_GEMM_PROBED
+    if _LIB_GEMM_PROBED is None:
+        try:
+            a = torch.ones(16, 16, dtype=torch.bfloat16, device="cuda")
+            o = torch.empty(16, 16, dtype=torch.float32, device="cuda")
+            torch.mm(a, a, out_dtype=torch.float32, out=o)
+            _LIB_GEMM_PROBED = bool(abs(float(o[0, 0]) - 16.0) < 1e-3)
+        except Exception:
+            _LIB_GEMM_PROBED = False
+    return _LIB_GEMM_PROBED
+
+
 def use_lib_gemm(M: int, N: int, K: int) -> bool:
-    return LIB_GEMM and 2.0 * M * N * K >= LIB_GEMM_MIN_FLOP
+    return LIB_GEMM and 2.0 * M * N * K >= LIB_GEMM_MIN_FLOP and _lib_gemm_available()
 
 
 def lib_gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> None:
