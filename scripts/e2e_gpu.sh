@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 algo=${1:-ape_x}
-conf=config/all.conf; [ "$algo" = r2d2 ] && conf=config/all_r2d2.conf
+conf=config/all.conf; [ "$algo" = r2d2 ] && conf=config/all_r2d2.conf; [ -n "${DRL_E2E_CONF:-}" ] && conf=$DRL_E2E_CONF
 save=$(mktemp -d /tmp/drl_e2e_XXXX)
 extra="--batch-size 32 --start-memory-size 64"
 abatch=16
