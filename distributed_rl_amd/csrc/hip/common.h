@@ -96,13 +96,15 @@ struct StepState {
     float beta0, beta_inc;       // beta = min(1, beta0 + beta_inc * t)
     float total_prio;            // root of the tree at sample time
     long long n_items;           // live items at sample time
-    float loss;                  // last loss (written by the TD kernel)
+    float loss;                  // loss of EVEN steps (written / atomically summed by the TD kernels, see loss_slot)
     float grad_norm;             // last global grad norm (written by the optimizer)
     float max_w;                 // max IS weight of the last batch (pre-normalisation)
-    float pad;
+    float loss_odd;              // loss of ODD steps: two slots, so the sampler of step t+1 may run (and clear its slot) before
+                                 // the host has read the loss of step t
     // max IS weight of the batch being sampled, as float bits (positive floats order like unsigned ints), accumulated
     // with atomicMax by the sampling kernel: slot [step & 1] belongs to this step, the other one is cleared for the next
     unsigned wmax_bits[2];
 };
+__device__ __forceinline__ float* loss_slot(StepState* st, unsigned long long step) { return (step & 1) ? &st->loss_odd : &st->loss; }
 static_assert(sizeof(StepState) == 64, "StepState is mirrored by ops/hip.py (STEP_STATE_BYTES)");
 

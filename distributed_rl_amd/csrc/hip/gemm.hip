@@ -1051,6 +1051,22 @@ struct TreeBody {
     }
 };
 
+// PER sample of the NEXT step as a body (4 draws per 256-thread block): rides along with the conv1 backward launch and
+// writes into the replay's "next" buffers, which the optimizer launch hands over (optim.hip CopyExtra) - the conv1
+// weight gradient of the same launch still reads the CURRENT frame offsets.
+struct SampleBody {
+    typedef SampleArgs Args;
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        sample_block(g.tr, g.st, g.seed, g.B, g.idx_out, g.prio_out, g.gen, g.gen_out, g.frame_off, g.frame_bytes, g.begin_n_items,
+                     g.is_n_scale, block, reinterpret_cast<float*>(smem));
+    }
+    static int plan(Args& g, const void* extra, size_t* lds) {
+        const int n = fill_sample_args(extra, &g);
+        if (n > 0 && *lds < 64) *lds = 64;
+        return n;
+    }
+};
+
 struct NoBody {
     struct Args { int unused; };
     static __device__ __forceinline__ void run(const Args&, int, uint8_t*) {}
@@ -1127,15 +1143,15 @@ DRL_API int drl_fc_bwd(const void* dy, const void* x, const void* w, float* dw, 
 // which is also the ReLU mask of dX). dY = d(pre-activation) of this layer's output, NHWC bf16.
 template <class WG, class BOp>
 static int conv_bwd_12(const BOp& B, int cout, int kdim, float scale, const void* dy, float* dw, float* db, int splits,
-                       const TreeExtra* extra, hipStream_t s) {
+                       const TreeExtra* extra, const void* sample, hipStream_t s) {
     size_t lds = 0;
-    typename WG::Args aw; ColsumBody::Args ac; TreeBody::Args at;
+    typename WG::Args aw; ColsumBody::Args ac; TreeBody::Args at; SampleBody::Args as;
     const int nt = TreeBody::plan(at, extra, &lds);
+    const int ns = SampleBody::plan(as, sample, &lds);
     const int nw = WG::plan(aw, DenseOp{(const bf16_t*)dy, cout, B.rows}, B, cout, kdim, B.rows, splits,
                             make_epi(dw, kdim, nullptr, nullptr, 0, scale, EPI_OUT_F32 | EPI_ATOMIC), 0, &lds);
     const int nc = ColsumBody::plan(ac, dy, B.rows, cout, db, &lds);
-    NoBody::Args none{0};
-    return launch_multi<WG, ColsumBody, TreeBody, NoBody>(aw, nw, ac, nc, at, nt, none, 0, lds, s);
+    return launch_multi<WG, ColsumBody, TreeBody, SampleBody>(aw, nw, ac, nc, at, nt, as, ns, lds, s);
 }
 
 template <int H, int W, int KS, int S, int CI, int CO, int BM, int BN, int WM, int WN, class COp, int WBK, int WD, bool WG_FIRST>
@@ -1163,8 +1179,10 @@ static int conv_bwd_3(const void* x, int frames, const void* dy, const void* w, 
 
 // extra (optional, host pointer to a TreeExtra): a stage of the PER priority write-back to run inside the same launch.
 DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, int frames, const void* dy, const void* w, float* dw,
-                         float* db, void* dx, int splits, const void* extra_, hipStream_t s) {
+                         float* db, void* dx, int splits, const void* extra_, const void* sample, hipStream_t s) {
+    // sample (optional, layer 1 only; host pointer to a SampleExtra): the next step's PER batch drawn inside this launch
     const TreeExtra* extra = (const TreeExtra*)extra_;
+    if (sample && layer != 1) return -1;
     if (frames <= 0) return -1;
     const int variant = splits >> 16;          // tile variant in the high half (tuning hook), split count in the low half
     splits &= 0xffff;
@@ -1172,9 +1190,9 @@ DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, i
         const int rows = frames * Conv1Op::OH * Conv1Op::OW;
         if (frame_off)
             return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1OffOp>>(Conv1OffOp{x, frame_off, rows}, 32, Conv1Op::K,
-                                                                                              1.0f / 255.0f, dy, dw, db, splits, extra, s);
+                                                                                              1.0f / 255.0f, dy, dw, db, splits, extra, sample, s);
         return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1Op>>(Conv1Op{x, nullptr, rows}, 32, Conv1Op::K,
-                                                                                       1.0f / 255.0f, dy, dw, db, splits, extra, s);
+                                                                                       1.0f / 255.0f, dy, dw, db, splits, extra, sample, s);
     }
 #define CB2(bk, d, f) return conv_bwd_3<20, 20, 4, 2, 32, 64, 128, 32, 4, 1, Conv2Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)
 #define CB3(bk, d, f) return conv_bwd_3<9, 9, 3, 1, 64, 64, 128, 64, 2, 2, Conv3Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)

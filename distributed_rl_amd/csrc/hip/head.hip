@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_apex_td_dh(const float* __restrict__ q
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += s_loss[i];
-        atomicAdd(&st->loss, t / (float)B);                     // zeroed by the sampling kernel of this step
+        atomicAdd(loss_slot(st, st->step), t / (float)B);       // slot zeroed by the sampling kernel of this step
         if (blockIdx.x == 0) st->max_w = __uint_as_float(st->wmax_bits[st->step & 1]);
     }
 }

@@ -7,6 +7,7 @@
 // update to the fp32 master weights and (d) writes the bf16 copy the MFMA kernels read — so there is no separate
 // cast pass and no host synchronisation for the norm.
 #include "common.h"
+#include "sumtree_body.h"
 
 #define NPART 1024
 
@@ -34,17 +35,40 @@ __device__ __forceinline__ float clip_coef_from_partials(const float* __restrict
     return max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
 }
 
+// Hand-over of the pre-drawn PER batch (see SampleBody in gemm.hip): up to four small device-to-device copies done by ONE
+// extra block of the optimizer launch. Host-side description, mirrored by ops/hip.py (ctypes).
+struct CopyExtra {
+    int n, pad;
+    void* dst[4];
+    const void* src[4];
+    long long bytes[4];            // multiples of 16
+};
+static_assert(sizeof(CopyExtra) == 104, "CopyExtra is mirrored by ops/hip.py (ctypes)");
+
 // mode 0: RMSprop (alpha, eps; no momentum, not centered).  mode 1: Adam (beta1, beta2, eps, bias correction).
+// The last n_opt blocks update the parameters; one optional block in front of them copies the pre-drawn PER batch of the
+// next step into the live sample buffers (by the time the optimizer runs nothing of the current step reads them any more).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m1,
                                                  float* __restrict__ m2, bf16_t* __restrict__ p_bf16, long long n,
                                                  const float* __restrict__ partial, int n_partial, float grad_scale,
                                                  float max_norm, float lr, float a1, float a2, float eps, StepState* st,
-                                                 int zero_grad) {
+                                                 int zero_grad, int n_opt, CopyExtra cp) {
     __shared__ float red[32];
+    // optional extra block in front of the update blocks: hands the pre-drawn batch of the next step over (copies)
+    const int n_smp = (int)gridDim.x - n_opt;
+    if ((int)blockIdx.x < n_smp) {
+        for (int c = 0; c < cp.n; ++c) {
+            const uint4* src = reinterpret_cast<const uint4*>(cp.src[c]);
+            uint4* dst = reinterpret_cast<uint4*>(cp.dst[c]);
+            for (long long i = threadIdx.x; i < cp.bytes[c] / 16; i += blockDim.x) dst[i] = src[i];
+        }
+        return;
+    }
+    const int ob = (int)blockIdx.x - n_smp;          // index among the update blocks
     float norm;
     const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm) * grad_scale;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && st) st->grad_norm = norm;
+    if (ob == 0 && threadIdx.x == 0 && st) st->grad_norm = norm;
     float bc1 = 1.f, bc2s = 1.f;
     if (MODE == 1) {
         const float t = (float)(st->step + 1);
@@ -57,7 +81,7 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
     float4* m14 = reinterpret_cast<float4*>(m1);
     float4* m24 = reinterpret_cast<float4*>(m2);
     uint2* pb4 = reinterpret_cast<uint2*>(p_bf16);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)ob * blockDim.x + threadIdx.x; i < n4; i += (long long)n_opt * blockDim.x) {
         float4 pv = p4[i], gv = g4[i];
         // the split-K / bias-gradient kernels of the NEXT step accumulate with atomics: hand them a zeroed buffer from
         // this pass (the line is in flight anyway) instead of a separate memset launch
@@ -115,12 +139,21 @@ DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART 
     return (int)hipGetLastError();
 }
 
+// copies (optional, host pointer to a CopyExtra): done by one extra block of this launch.
 DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long long n, const float* partial,
                              int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
-                             int zero_grad, hipStream_t s) {
+                             int zero_grad, const void* copies, hipStream_t s) {
     if (n <= 0 || (n & 3)) return -1;
-    k_opt_step<0><<<grid_for(n), 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
-                                              lr, alpha, 0.f, eps, (StepState*)st, zero_grad);
+    CopyExtra cp;
+    cp.n = 0;
+    if (copies) {
+        cp = *(const CopyExtra*)copies;
+        if (cp.n < 0 || cp.n > 4) return -2;
+        for (int c = 0; c < cp.n; ++c) if (cp.bytes[c] & 15) return -2;
+    }
+    const int no = grid_for(n), ns = cp.n > 0 ? 1 : 0;
+    k_opt_step<0><<<no + ns, 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
+                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp);
     return (int)hipGetLastError();
 }
 
@@ -128,8 +161,11 @@ DRL_API int drl_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, 
                           int n_partial, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           void* st, int zero_grad, hipStream_t s) {
     if (n <= 0 || (n & 3) || !st) return -1;
-    k_opt_step<1><<<grid_for(n), 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
-                                              beta1, beta2, eps, (StepState*)st, zero_grad);
+    CopyExtra cp;
+    cp.n = 0;
+    const int no = grid_for(n);
+    k_opt_step<1><<<no, 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
+                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp);
     return (int)hipGetLastError();
 }
 

@@ -29,78 +29,14 @@ __global__ void k_step_end(StepState* st) {
     if (threadIdx.x == 0) st->step += 1;
 }
 
-// One wave per draw.
+// One wave per draw: see sample_block (sumtree_body.h).
 __global__ __launch_bounds__(1024) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
                                                int* __restrict__ idx_out, float* __restrict__ prio_out,
                                                const int* __restrict__ gen, int* __restrict__ gen_out,
                                                long long* __restrict__ frame_off, long long frame_bytes,
                                                const long long* __restrict__ begin_n_items, float is_n_scale) {
     __shared__ float s_w[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-    float w_is = 0.f;                                      // this draw's un-normalised IS weight (lane 0)
-    if (b < B) {                                           // whole waves take the branch together
-    Philox ph(seed);
-    // fused step_begin (learner engines): the Philox counter of step t is rng_ctr + t + 1 (nobody writes rng_ctr or step
-    // while this kernel runs), and wave 0 publishes beta / n_items for the kernels that follow
-    unsigned long long ctr = st->rng_ctr;
-    const unsigned long long t = st->step;
-    if (begin_n_items) {
-        ctr += t + 1;
-        if (b == 0 && lane == 0) {
-            st->beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
-            st->n_items = *begin_n_items;
-            if (is_n_scale > 0.f) { st->wmax_bits[(t + 1) & 1] = 0u; st->loss = 0.f; }   // next step's slot; loss is atomically summed
-        }
-    }
-    float top_sum = 0.f;
-    uint4 r = ph(ctr, (unsigned long long)b);
-    uint32_t rnd[4] = {r.x, r.y, r.z, r.w};
-    long long node = 0;
-    float leaf_p = 0.f;
-    for (int lvl = tr.n_levels - 1, k = 0; lvl >= 0; --lvl, ++k) {
-        if (k == 4) { r = ph(ctr, (unsigned long long)b + ((unsigned long long)1 << 40)); rnd[0] = r.x; rnd[1] = r.y; rnd[2] = r.z; rnd[3] = r.w; k = 0; }
-        float v = tr.base[tr.off[lvl] + node * 64 + lane];
-        float incl = wave_scan_incl(v, lane);
-        float S = __shfl(incl, 63, WAVE);
-        if (lvl == tr.n_levels - 1) { top_sum = S; if (b == 0 && lane == 0) st->total_prio = S; }
-        float u = u01(rnd[k]) * S;
-        unsigned long long hit = __ballot(incl > u && v > 0.f);
-        unsigned long long nz = __ballot(v > 0.f);
-        int pick;
-        if (hit) pick = __ffsll((long long)hit) - 1;
-        else if (nz) pick = 63 - __clzll((long long)nz);          // float edge: take the last non-empty child
-        else pick = 0;                                             // empty tree
-        leaf_p = __shfl(v, pick, WAVE);
-        node = node * 64 + pick;
-    }
-    if (lane == 0) {
-        int i = (int)(node < tr.cap ? node : tr.cap - 1);
-        idx_out[b] = i;
-        prio_out[b] = leaf_p;
-        if (begin_n_items && is_n_scale > 0.f && leaf_p > 0.f && top_sum > 0.f) {
-            // un-normalised IS weight (N p / total)^-beta of this draw -> running max of the batch (consumed by the fused
-            // TD kernel, head.hip k_apex_td_dh, which therefore needs no batch-wide reduction of its own)
-            const float beta = fminf(1.0f, st->beta0 + st->beta_inc * (float)t);
-            w_is = __powf((float)(*begin_n_items) * is_n_scale * leaf_p / top_sum, -beta);
-        }
-        if (gen_out) gen_out[b] = gen ? gen[i] : 0;
-        if (frame_off) {                                   // byte offsets of s and s' in the frame store
-            frame_off[b] = (long long)i * frame_bytes;
-            frame_off[B + b] = ((long long)tr.cap + i) * frame_bytes;
-        }
-    }
-    }
-    // one atomicMax per BLOCK: same-address atomics serialise in L2 (~35 ns each), 512 of them doubled this kernel's time
-    if (begin_n_items && is_n_scale > 0.f) {
-        if (lane == 0) s_w[wave] = w_is;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float m = 0.f;
-            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, s_w[i]);
-            if (m > 0.f) atomicMax(&st->wmax_bits[st->step & 1], __float_as_uint(m));
-        }
-    }
+    sample_block(tr, st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes, begin_n_items, is_n_scale, blockIdx.x, s_w);
 }
 
 // Leaves <- new priorities (dropped when the slot generation changed since sampling).

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void k_apex_td(const float* __restrict__ q_on
         if (w_out) w_out[b] = w;
     }
     loss = block_sum(loss, red);
-    if (threadIdx.x == 0) { st->loss = loss / (float)B; st->max_w = wmax; }
+    if (threadIdx.x == 0) { *loss_slot(st, st->step) = loss / (float)B; st->max_w = wmax; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_is_weights(const float* __restrict__ p
         float p = p_sampled[b];
         w_out[b] = (p > 0.f && total > 0.f) ? __powf(N * p / total, -beta) * inv : 0.f;
     }
-    if (threadIdx.x == 0) { st->max_w = wmax; st->loss = 0.f; }
+    if (threadIdx.x == 0) { st->max_w = wmax; *loss_slot(st, st->step) = 0.f; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(128) void k_r2d2_td(const float* __restrict__ q_on,
     if (threadIdx.x == 0) {
         new_prio[b] = eta * smax + (1.0f - eta) * ssum / fmaxf(cnt, 1.0f);
         if (seq_loss_out) seq_loss_out[b] = s2;
-        atomicAdd(&st->loss, s2 * w / (float)B);
+        atomicAdd(loss_slot(st, st->step), s2 * w / (float)B);
     }
 }
 

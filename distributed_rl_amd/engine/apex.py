@@ -97,6 +97,11 @@ class ApexEngine:
         import os as _os
         self.overlap_comm = _os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
+        # software-pipelined sampler (needs the fused path: step_end must have run before the optimizer launch)
+        self.presample = self.fused_bwd and B % 4 == 0 and _os.environ.get("DRL_PRESAMPLE", "1") != "0"
+        if self.presample:
+            replay._next_buffers()                                        # allocate now, never inside a graph capture
+        self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
         # (online forward -> TD -> dgrad chain); see engine/streams.py
@@ -140,8 +145,10 @@ class ApexEngine:
         ``fc1.w`` to the end of the flat buffer (97.6 % of the parameters) is final - multi-GPU runs start its
         all-reduce here, under the conv backward that follows."""
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
-        # step_begin fused; G was zeroed by the optimizer. fused_bwd: the sampler also accumulates the max IS weight
-        r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
+        # step_begin fused; G was zeroed by the optimizer. fused_bwd: the sampler also accumulates the max IS weight.
+        # presample: from the second step on the batch was already drawn by the previous step's optimizer launch.
+        if not (self.presample and self._primed):
+            r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
         with self._fork(0):                                        # target net on s' || online net on [s ; s']
             torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
         torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
@@ -184,8 +191,11 @@ class ApexEngine:
                        extra=r.update_stage(1, self.new_prio))
             H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), self.d1, B, splits=sp,
                        extra=r.update_stage(2, self.new_prio, end_state=self.st))
+            # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
+            # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
+            # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
             H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
-                       splits=4 * sp)
+                       splits=4 * sp, sample=r.sample_extra(self.st, self.n_scale) if self.presample else None)
             self._join()
             return
         with self._fork(1):                                        # conv3 dW, db || conv3 dX
@@ -214,7 +224,9 @@ class ApexEngine:
         cfg = self.cfg
         H.grad_sumsq(self.G.flat, self.partial)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
-                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True)
+                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
+                       copies=self.replay.handover_extra() if self.presample else None)
+        self._primed = self.presample
         if not self.fused_bwd:                                      # fused: done inside the conv backward launches
             self.replay.update(self.new_prio, end_state=self.st)    # step_end fused into the tree rebuild
 

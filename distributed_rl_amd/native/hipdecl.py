@@ -21,7 +21,7 @@ SIGS = {
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
     "drl_grad_sumsq": [P, L, P, POINTER(c_int), P],
-    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P],
     "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P],
     "drl_cast_bf16": [P, P, L, P],
     # head.hip
@@ -35,7 +35,7 @@ SIGS = {
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
-    "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P],
+    "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P, P],
     "drl_fc_bwd": [P, P, P, P, P, P, I, I, I, P, P, I, P, P, P, P, I, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip

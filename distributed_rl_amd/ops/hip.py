@@ -58,9 +58,12 @@ def read_step_state(st: torch.Tensor) -> dict:
     b = bytes(st.cpu().numpy().tobytes())
     step, ctr, beta, beta0, beta_inc, total = struct.unpack_from("<QQffff", b, 0)
     n_items, = struct.unpack_from("<q", b, 32)
-    loss, gnorm, max_w = struct.unpack_from("<fff", b, 40)
+    loss_even, gnorm, max_w, loss_odd = struct.unpack_from("<ffff", b, 40)
+    # two loss slots by step parity: "loss" = the last COMPLETED step (step already advanced by step_end), "loss_cur" = the
+    # step in progress (raw-kernel tests that read before step_end)
+    slots = (loss_even, loss_odd)
     return dict(step=step, rng_ctr=ctr, beta=beta, beta0=beta0, beta_inc=beta_inc, total_prio=total, n_items=n_items,
-                loss=loss, grad_norm=gnorm, max_w=max_w)
+                loss=slots[(step - 1) & 1] if step > 0 else loss_even, loss_cur=slots[step & 1], grad_norm=gnorm, max_w=max_w)
 
 
 def step_begin(st: torch.Tensor, n_items: torch.Tensor) -> None:
@@ -194,10 +197,12 @@ def grad_sumsq(g: torch.Tensor, partial: torch.Tensor) -> int:
 
 
 def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st,
-                 zero_grad: bool = False) -> None:
-    """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch)."""
+                 zero_grad: bool = False, copies: Optional["CopyExtra"] = None) -> None:
+    """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch). ``copies``
+    (see copy_extra) are done by one extra block of the same launch."""
     _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
-                                      max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0, _s()), "rmsprop_step")
+                                      max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0,
+                                      ctypes.byref(copies) if copies is not None else None, _s()), "rmsprop_step")
 
 
 def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st,
@@ -302,6 +307,54 @@ FC_BWD_VARIANT = 5
 CONV_BWD_VARIANT = {1: 0, 2: 4, 3: 2}
 
 
+class CopyExtra(ctypes.Structure):
+    """ctypes mirror of ``CopyExtra`` (csrc/hip/optim.hip): up to four small device copies done by one extra block of the
+    optimizer launch (hand-over of the pre-drawn PER batch)."""
+    _fields_ = [("n", ctypes.c_int), ("pad", ctypes.c_int), ("dst", ctypes.c_void_p * 4), ("src", ctypes.c_void_p * 4),
+                ("bytes", ctypes.c_longlong * 4)]
+
+
+def copy_extra(pairs) -> CopyExtra:
+    """pairs = [(dst, src), ...] (<= 4, same shapes / dtypes, byte sizes multiples of 16)."""
+    e = CopyExtra()
+    e.n = len(pairs)
+    assert e.n <= 4
+    for i, (d, s_) in enumerate(pairs):
+        nb = d.numel() * d.element_size()
+        assert d.dtype == s_.dtype and d.numel() == s_.numel() and nb % 16 == 0 and d.is_contiguous() and s_.is_contiguous()
+        e.dst[i], e.src[i], e.bytes[i] = d.data_ptr(), s_.data_ptr(), nb
+    return e
+
+
+class SampleExtra(ctypes.Structure):
+    """ctypes mirror of ``SampleExtra`` (csrc/hip/sumtree_body.h): the PER sample of the NEXT step, drawn by extra blocks
+    of the conv1 backward launch (conv_bwd(1, ..., sample=...))."""
+    _fields_ = [("kind", ctypes.c_int), ("n_levels", ctypes.c_int), ("base", ctypes.c_void_p),
+                ("off", ctypes.c_longlong * 6), ("cap", ctypes.c_longlong), ("st", ctypes.c_void_p),
+                ("seed", ctypes.c_ulonglong), ("B", ctypes.c_int), ("pad", ctypes.c_int), ("idx_out", ctypes.c_void_p),
+                ("prio_out", ctypes.c_void_p), ("gen", ctypes.c_void_p), ("gen_out", ctypes.c_void_p),
+                ("frame_off", ctypes.c_void_p), ("frame_bytes", ctypes.c_longlong), ("begin_n_items", ctypes.c_void_p),
+                ("is_n_scale", ctypes.c_float), ("pad2", ctypes.c_float)]
+
+
+def sample_extra(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
+                 prio_out: torch.Tensor, gen, gen_out, frame_off, frame_bytes: int, begin_n_items: torch.Tensor,
+                 is_n_scale: float) -> SampleExtra:
+    """Arguments of ``sumtree_sample(..., begin_n_items=..., is_n_scale=...)`` as a record for ``conv_bwd(1, ..., sample=...)``."""
+    _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
+    e = SampleExtra()
+    e.kind, e.n_levels, e.base, e.cap = 1, lay.n_levels, tree.data_ptr(), lay.capacity
+    for i in range(6):
+        e.off[i] = int(lay.offsets[i]) if i < lay.n_levels else 0
+    e.st, e.seed, e.B = st.data_ptr(), int(seed), idx_out.numel()
+    e.idx_out, e.prio_out = idx_out.data_ptr(), prio_out.data_ptr()
+    e.gen = gen.data_ptr() if gen is not None else None
+    e.gen_out = gen_out.data_ptr() if gen_out is not None else None
+    e.frame_off = frame_off.data_ptr() if frame_off is not None else None
+    e.frame_bytes, e.begin_n_items, e.is_n_scale = int(frame_bytes), begin_n_items.data_ptr(), float(is_n_scale)
+    return e
+
+
 class TreeExtra(ctypes.Structure):
     """ctypes mirror of ``TreeExtra`` (csrc/hip/gemm.hip): one stage of the PER priority write-back that rides along with
     a fused conv-backward launch. kind 1 = leaves + level 1, 2 = levels >= 2 (+ step_end), 3 = step_end only."""
@@ -329,7 +382,8 @@ def tree_extra(kind: int, tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor
 
 def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], dw: torch.Tensor, db: torch.Tensor,
              dx: Optional[torch.Tensor], frames: int, frame_off: Optional[torch.Tensor] = None, splits: int = 32,
-             variant: Optional[int] = None, extra: Optional["TreeExtra"] = None) -> None:
+             variant: Optional[int] = None, extra: Optional["TreeExtra"] = None,
+             sample: Optional["SampleExtra"] = None) -> None:
     """Whole backward of a conv layer as ONE launch (k_multi in gemm.hip): implicit input gradient dx (layers 2/3, masked
     by relu'(x)), split-K weight gradient accumulated into the ZEROED dw, bias gradient accumulated into the zeroed db.
     x = the layer's forward input (layer 1: uint8 frames, optionally via frame_off byte offsets)."""
@@ -338,8 +392,8 @@ def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Te
         _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
     variant = CONV_BWD_VARIANT[layer] if variant is None else variant
     _ck(native.hip().drl_conv_bwd(layer, _p(x), _p(frame_off), frames, _p(dy), _p(w), _p(dw), _p(db), _p(dx),
-                                  splits | (variant << 16), ctypes.byref(extra) if extra is not None else None, _s()),
-        "conv_bwd")
+                                  splits | (variant << 16), ctypes.byref(extra) if extra is not None else None,
+                                  ctypes.byref(sample) if sample is not None else None, _s()), "conv_bwd")
 
 
 def fc_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db: torch.Tensor, dx: torch.Tensor,

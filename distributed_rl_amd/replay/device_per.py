@@ -120,6 +120,25 @@ class DevicePER:
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
                          self.frame_bytes, begin_n_items=self.n_items if begin else None, is_n_scale=is_n_scale)
 
+    def _next_buffers(self):
+        if getattr(self, "_nxt", None) is None:
+            self._nxt = (torch.zeros_like(self.idx), torch.zeros_like(self.prio), torch.zeros_like(self.gen_s),
+                         torch.zeros_like(self.frame_off))
+        return self._nxt
+
+    def sample_extra(self, st: torch.Tensor, is_n_scale: float):
+        """``sample(st, begin=True, is_n_scale=...)`` as a record that draws into the NEXT-batch buffers: the learner engine
+        hands it to the conv1 backward launch (ops.hip.conv_bwd(1, ..., sample=...)), which still reads the current
+        frame offsets, and ``handover_extra`` to the optimizer launch."""
+        idx, prio, gen_s, foff = self._next_buffers()
+        return H.sample_extra(self.tree, self.lay, st, self.seed, idx, prio, self.gen, gen_s, foff, self.frame_bytes,
+                              self.n_items, is_n_scale)
+
+    def handover_extra(self):
+        """Copies next-batch buffers -> live sample buffers (ops.hip.rmsprop_step(copies=...))."""
+        idx, prio, gen_s, foff = self._next_buffers()
+        return H.copy_extra([(self.idx, idx), (self.prio, prio), (self.gen_s, gen_s), (self.frame_off, foff)])
+
     def update(self, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None) -> None:
         """Write back priorities of the last sample; slots overwritten since are skipped (generation check).
         ``end_state`` fuses step_end into the tree rebuild launch."""

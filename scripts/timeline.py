@@ -12,7 +12,7 @@ def main():
     marker = sys.argv[2] if len(sys.argv) > 2 else "k_sample"
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
+    idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     a, b = idx[-3], idx[-2]
     t0 = int(rows[a]["Start_Timestamp"])
     tot = 0

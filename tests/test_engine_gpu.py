@@ -73,6 +73,7 @@ def test_apex_engine_step_matches_oracle():
             p.grad.copy_(grads[name])
     gn = torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
     opt.step()
+    idx_used = rep.idx.clone()        # the optimizer launch also draws the NEXT step's batch into rep.idx (presample)
     eng._optimize()
     torch.cuda.synchronize()
     assert eng.stats()["grad_norm"] == pytest.approx(float(gn), rel=1e-3)
@@ -80,9 +81,14 @@ def test_apex_engine_step_matches_oracle():
     for name, p in model.named_parameters():
         torch.testing.assert_close(new[name], p.detach(), rtol=1e-4, atol=1e-6)
     # priorities were written back into the tree at the sampled slots
-    leaves = rep.tree[:rep.capacity][rep.idx.long()].cpu()
+    leaves = rep.tree[:rep.capacity][idx_used.long()].cpu()
     torch.testing.assert_close(leaves, eng.new_prio.cpu())
     assert eng.stats()["step"] == 1
+    if eng.presample:                 # the pre-drawn batch is what a start-of-step sampler would draw for step 1
+        pre_idx, pre_prio = rep.idx.clone(), rep.prio.clone()
+        rep.sample(eng.st, begin=True, is_n_scale=eng.n_scale)
+        torch.cuda.synchronize()
+        assert torch.equal(pre_idx, rep.idx) and torch.equal(pre_prio, rep.prio)
 
 
 def test_apex_engine_graph_equals_eager_and_learns():

@@ -179,7 +179,7 @@ def test_apex_td(hip, B, A):
     torch.testing.assert_close(newp.cpu(), td.prio, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(dq.cpu(), td.dq, rtol=2e-4, atol=1e-8)
     s = H.read_step_state(st)
-    assert s["loss"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
+    assert s["loss_cur"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
 
 
 @pytest.mark.parametrize("B,A", [(512, 4), (50, 18), (33, 6)])
@@ -213,7 +213,7 @@ def test_apex_td_dh_fused_matches_td_plus_head_bwd(hip, B, A):
         dh0 = torch.zeros(B, 1024, dtype=torch.bfloat16, device=DEV)
         z = [torch.zeros(A, 512, device=DEV), torch.zeros(A, device=DEV), torch.zeros(1, 512, device=DEV), torch.zeros(1, device=DEV)]
         H.head_bwd(dq0, hq, w_adv, w_val, dh0, *z, parts=1)
-        assert s1["max_w"] == pytest.approx(s0["max_w"], rel=1e-5) and s1["loss"] == pytest.approx(s0["loss"], rel=1e-4)
+        assert s1["max_w"] == pytest.approx(s0["max_w"], rel=1e-5) and s1["loss_cur"] == pytest.approx(s0["loss_cur"], rel=1e-4)
         torch.testing.assert_close(dq1, dq0, rtol=1e-5, atol=1e-9)
         torch.testing.assert_close(pr1, pr0, rtol=1e-6, atol=0)
         torch.testing.assert_close(dh1.float(), dh0.float(), rtol=2e-2, atol=1e-7)
@@ -250,7 +250,7 @@ def test_r2d2_td(hip, done_offset):
     torch.testing.assert_close(sl.cpu(), td.seq_loss, rtol=2e-4, atol=1e-5)
     torch.testing.assert_close(newp.cpu(), td.prio, rtol=2e-4, atol=1e-5)
     torch.testing.assert_close(dq.cpu(), td.dq, rtol=2e-3, atol=1e-5)
-    assert H.read_step_state(st)["loss"] == pytest.approx(float(td.loss), rel=5e-4)
+    assert H.read_step_state(st)["loss_cur"] == pytest.approx(float(td.loss), rel=5e-4)
 
 
 # ---- optimizer -----------------------------------------------------------------------------------------
