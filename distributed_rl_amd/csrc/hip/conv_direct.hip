@@ -39,14 +39,30 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 // ---------------------------------------------------------------------------------------------------------------
 // conv1: u8 [*,84,84,4] (dense batch, or frames of a replay store addressed by byte offsets) -> bf16 [n,20,20,32]
 // ---------------------------------------------------------------------------------------------------------------
+// A second network (its own frame offsets / weights / bias / output / row count, same frame store x) may ride along in
+// the same launch: blocks [nblk1, gridDim.x) work on it (Ape-X learner: online net on [s ; s'] + target net on s' as ONE
+// launch instead of two launches on two streams).
+struct Conv1Net {
+    const long long* frame_off;
+    const bf16_t* w;
+    const float* bias;
+    bf16_t* out;
+    int M, per;
+};
+
 template <bool OFF>
-__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, const long long* __restrict__ frame_off,
-                                                     const bf16_t* __restrict__ w, const float* __restrict__ bias,
-                                                     bf16_t* __restrict__ out, int M, int per) {
+__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, int nblk1) {
+    const bool second = (int)blockIdx.x >= nblk1;                      // block-uniform
+    const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
+    const bf16_t* __restrict__ w = second ? n2.w : n1.w;
+    const float* __restrict__ bias = second ? n2.bias : n1.bias;
+    bf16_t* __restrict__ out = second ? n2.out : n1.out;
+    const int M = second ? n2.M : n1.M, per = second ? n2.per : n1.per;
+    const int blk = second ? (int)blockIdx.x - nblk1 : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int ntiles = (M + 15) >> 4;
     // every wave owns `per` CONSECUTIVE 16-row tiles (neighbouring output pixels overlap in the input: L1/L2 hits)
-    const int t0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
+    const int t0 = (blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
     if (t0 >= ntiles) return;                       // wave-uniform: no barriers in this kernel
     bf16x8 wf[2][8];
 #pragma unroll
@@ -241,8 +257,9 @@ DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const f
         const int M = frames * 400;
         int grid;
         const int per = plan((M + 15) / 16, 256 * 16, 4, &grid);
-        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
-        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, nullptr, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
+        const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
+        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
+        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
     } else if (layer == 2) {
         if ((long long)frames * 20 * 20 * 32 >= (1LL << 32)) return -8;
         const int M = frames * 81;
@@ -262,5 +279,22 @@ DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const f
             default: launch_direct<9, 9, 64, 3, 1, 1, 4>(x, w, bias, out, M, s); break;
         }
     } else return -1;
+    return (int)hipGetLastError();
+}
+
+// conv1 of TWO networks over frames of one store in one launch (both addressed through byte offsets).
+DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int frames1, const void* w1, const float* bias1,
+                               void* out1, const long long* frame_off2, int frames2, const void* w2, const float* bias2,
+                               void* out2, hipStream_t s) {
+    if (frames1 <= 0 || frames2 <= 0 || !frame_off1 || !frame_off2) return -1;
+    int g1, g2;
+    const int slots = 256 * 16;
+    const int M1 = frames1 * 400, M2 = frames2 * 400;
+    // split the resident wave slots in proportion to the work so both networks finish together
+    const int s1 = (int)((long long)slots * M1 / (M1 + M2)), s2 = slots - s1;
+    const int per1 = plan((M1 + 15) / 16, s1 > 0 ? s1 : 1, 4, &g1), per2 = plan((M2 + 15) / 16, s2 > 0 ? s2 : 1, 4, &g2);
+    const Conv1Net n1{frame_off1, (const bf16_t*)w1, bias1, (bf16_t*)out1, M1, per1};
+    const Conv1Net n2{frame_off2, (const bf16_t*)w2, bias2, (bf16_t*)out2, M2, per2};
+    k_conv1_direct<true><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, g1);
     return (int)hipGetLastError();
 }

@@ -980,6 +980,25 @@ struct GemmBody {
     }
 };
 
+template <int BM, int BN, int WM, int WN, bool A_TR, bool B_TR, int NS, class AOp, class BOp>
+struct GldsBody {             // like GemmBody, LDS-DMA mainloop
+    struct Args { AOp a; BOp b; int Mo, No, Kc, kt_per, gx, gy; Epilogue ep; };
+    static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        const int bx = block % g.gx, r = block / g.gx, by = r % g.gy, bz = r / g.gy;
+        gemm_tile_glds<BM, BN, WM, WN, A_TR, B_TR, NS, AOp, BOp>(g.a, g.b, g.Mo, g.No, g.Kc, g.kt_per, g.ep, bx, by, bz, g.gx, g.gy, smem);
+    }
+    static int plan(Args& g, const AOp& a, const BOp& b, int Mo, int No, int Kc, int splits, const Epilogue& ep, int classes, size_t* lds) {
+        dim3 grid;
+        size_t need;
+        int kt_per;
+        if (int rc = plan_gemm<BM, BN, 64>(Mo, No, Kc, splits, ep, classes, &kt_per, &grid, &need)) return rc;
+        need = (size_t)NS * (BM + BN) * 64 * 2;
+        g.a = a; g.b = b; g.Mo = Mo; g.No = No; g.Kc = Kc; g.kt_per = kt_per; g.gx = grid.x; g.gy = grid.y; g.ep = ep;
+        if (need > *lds) *lds = need;
+        return (int)(grid.x * grid.y * grid.z);
+    }
+};
+
 struct ColsumBody {
     struct Args { const bf16_t* dy; long long total; int NC8, cpb; float* db; };
     static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
@@ -1081,6 +1100,25 @@ __global__ __launch_bounds__(NTHREADS) void k_multi(typename B0::Args a0, typena
     else if (b < e1) B1::run(a1, b - e0, smem);
     else if (b < e2) B2::run(a2, b - e1, smem);
     else B3::run(a3, b - e2, smem);
+}
+
+template <class B0, class B1, class B2, class B3>
+static int launch_multi_big(const typename B0::Args& a0, int n0, const typename B1::Args& a1, int n1, size_t lds, hipStream_t s) {
+    // two-body launch whose LDS may exceed 64 KB (the LDS-DMA bodies)
+    if (n0 < 0) return n0;
+    if (n1 < 0) return n1;
+    auto kern = k_multi<B0, B1, B2, B3>;
+    if (lds > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -6;
+            once = true;
+        }
+    }
+    typename B2::Args z2{};
+    typename B3::Args z3{};
+    kern<<<n0 + n1, NTHREADS, lds, s>>>(a0, a1, z2, z3, n0, n0 + n1, n0 + n1);
+    return (int)hipGetLastError();
 }
 
 template <class B0, class B1, class B2, class B3>
@@ -1348,4 +1386,49 @@ DRL_API int drl_lstm_bwd_step(const void* dh_head, const float* dh_rec_in, float
     k_lstm_bwd_step<<<dim3(H / 64, H / 64), NTHREADS, LDS, s>>>((const bf16_t*)dh_head, dh_rec_in, dh_rec_out, dh_rec_zero, dc_in,
                                                                 dc_out, (const bf16_t*)gates, c_t, c_prev, (bf16_t*)dgates, W, M);
     return (int)hipGetLastError();
+}
+
+// ---- forward of TWO networks per launch (Ape-X learner: online net + target net, same layer, different weights) -------
+// Same bodies as the single-network launches (conv2: register ring 128x64, conv3: LDS-DMA 128x64 x 3 stages, FC: LDS-DMA
+// 64x64 x 4 stages); no fork / join between two streams is needed any more.
+DRL_API int drl_conv_fwd_dual(int layer, const void* x1, int frames1, const void* w1, const float* bias1, void* out1,
+                              const void* x2, int frames2, const void* w2, const float* bias2, void* out2, hipStream_t s) {
+    if (frames1 <= 0 || frames2 <= 0) return -1;
+    size_t lds = 0;
+    if (layer == 2) {
+        typedef GemmBody<128, 64, 64, 2, 2, false, false, 2, Conv2Op, DenseOp> BD;
+        BD::Args a1, a2;
+        Conv2Op A1{x1, nullptr, frames1 * Conv2Op::OH * Conv2Op::OW}, A2{x2, nullptr, frames2 * Conv2Op::OH * Conv2Op::OW};
+        const int n1 = BD::plan(a1, A1, DenseOp{(const bf16_t*)w1, Conv2Op::K, 64}, A1.rows, 64, Conv2Op::K, 1,
+                                make_epi(out1, 64, bias1, nullptr, 0, 1.0f, EPI_RELU), 0, &lds);
+        const int n2 = BD::plan(a2, A2, DenseOp{(const bf16_t*)w2, Conv2Op::K, 64}, A2.rows, 64, Conv2Op::K, 1,
+                                make_epi(out2, 64, bias2, nullptr, 0, 1.0f, EPI_RELU), 0, &lds);
+        return launch_multi_big<BD, BD, NoBody, NoBody>(a1, n1, a2, n2, lds, s);
+    }
+    if (layer == 3) {
+        typedef GldsBody<128, 64, 2, 2, false, false, 3, Conv3Op, DenseOp> BD;
+        BD::Args a1, a2;
+        Conv3Op A1{x1, nullptr, frames1 * Conv3Op::OH * Conv3Op::OW}, A2{x2, nullptr, frames2 * Conv3Op::OH * Conv3Op::OW};
+        const int n1 = BD::plan(a1, A1, DenseOp{(const bf16_t*)w1, Conv3Op::K, 64}, A1.rows, 64, Conv3Op::K, 1,
+                                make_epi(out1, 64, bias1, nullptr, 0, 1.0f, EPI_RELU), 0, &lds);
+        const int n2 = BD::plan(a2, A2, DenseOp{(const bf16_t*)w2, Conv3Op::K, 64}, A2.rows, 64, Conv3Op::K, 1,
+                                make_epi(out2, 64, bias2, nullptr, 0, 1.0f, EPI_RELU), 0, &lds);
+        return launch_multi_big<BD, BD, NoBody, NoBody>(a1, n1, a2, n2, lds, s);
+    }
+    return -1;
+}
+
+// c_i[M_i][N] = relu(a_i[M_i][K] . w_i[N][K]^T + bias_i), i = 1, 2, one launch.
+DRL_API int drl_gemm_nt_dual(const void* a1, int M1, const void* w1, const float* bias1, void* c1, const void* a2, int M2,
+                             const void* w2, const float* bias2, void* c2, int N, int K, int flags, hipStream_t s) {
+    if ((K & 7) || (N % 64) || M1 <= 0 || M2 <= 0) return -4;
+    if ((long long)M1 * K >= (1LL << 32) || (long long)M2 * K >= (1LL << 32) || (long long)N * K >= (1LL << 32)) return -8;
+    typedef GldsBody<64, 64, 2, 2, false, false, 4, DenseOp, DenseOp> BD;
+    size_t lds = 0;
+    BD::Args g1, g2;
+    const int n1 = BD::plan(g1, DenseOp{(const bf16_t*)a1, K, M1}, DenseOp{(const bf16_t*)w1, K, N}, M1, N, K, 1,
+                            make_epi(c1, N, bias1, nullptr, 0, 1.0f, flags), 0, &lds);
+    const int n2 = BD::plan(g2, DenseOp{(const bf16_t*)a2, K, M2}, DenseOp{(const bf16_t*)w2, K, N}, M2, N, K, 1,
+                            make_epi(c2, N, bias2, nullptr, 0, 1.0f, flags), 0, &lds);
+    return launch_multi_big<BD, BD, NoBody, NoBody>(g1, n1, g2, n2, lds, s);
 }

@@ -20,15 +20,13 @@ __device__ __forceinline__ void load16_bf16(const bf16_t* p, float* out) {
     for (int i = 0; i < 8; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
-// grid = ceil(M/4), block = 256 (4 rows per block)
-__global__ __launch_bounds__(256) void k_head_fwd(const bf16_t* __restrict__ h, int M, int A, const bf16_t* __restrict__ w_adv,
-                                                 const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
-                                                 const float* __restrict__ b_val, float* __restrict__ q_out,
-                                                 int* __restrict__ action_out, const float* __restrict__ eps, int eps_mod,
-                                                 unsigned long long seed, const unsigned long long* __restrict__ ctr_ptr) {
+// one wave = one row
+__device__ __forceinline__ void head_fwd_row(const bf16_t* __restrict__ h, int row, int A, const bf16_t* __restrict__ w_adv,
+                                             const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
+                                             const float* __restrict__ b_val, float* __restrict__ q_out,
+                                             int* __restrict__ action_out, const float* __restrict__ eps, int eps_mod,
+                                             unsigned long long seed, const unsigned long long* __restrict__ ctr_ptr) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     float hv[16];
     load16_bf16(h + (long long)row * (2 * HID) + lane * 16, hv);
     const bool adv_half = lane < 32;
@@ -76,6 +74,28 @@ __global__ __launch_bounds__(256) void k_head_fwd(const bf16_t* __restrict__ h, 
             action_out[row] = act;
         }
     }
+}
+
+// grid = ceil(M/4), block = 256 (4 rows per block)
+__global__ __launch_bounds__(256) void k_head_fwd(const bf16_t* __restrict__ h, int M, int A, const bf16_t* __restrict__ w_adv,
+                                                 const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
+                                                 const float* __restrict__ b_val, float* __restrict__ q_out,
+                                                 int* __restrict__ action_out, const float* __restrict__ eps, int eps_mod,
+                                                 unsigned long long seed, const unsigned long long* __restrict__ ctr_ptr) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    head_fwd_row(h, row, A, w_adv, b_adv, w_val, b_val, q_out, action_out, eps, eps_mod, seed, ctr_ptr);
+}
+
+// Two networks in one launch (rows [0, M1) = network 1, [M1, M1 + M2) = network 2; Q values only).
+struct HeadNet { const bf16_t* h; const bf16_t* w_adv; const float* b_adv; const bf16_t* w_val; const float* b_val; float* q_out; int M; };
+__global__ __launch_bounds__(256) void k_head_fwd_dual(HeadNet n1, HeadNet n2, int A) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n1.M + n2.M) return;
+    const bool second = row >= n1.M;                       // wave-uniform
+    const HeadNet n = second ? n2 : n1;
+    if (second) row -= n1.M;
+    head_fwd_row(n.h, row, A, n.w_adv, n.b_adv, n.w_val, n.b_val, n.q_out, nullptr, nullptr, 0, 0ull, nullptr);
 }
 
 // dh[row][k] = relu'(h) * (k<512 ? sum_j dadv_j W_adv[j][k] : dval W_val[k-512]);  one wave per row.
@@ -230,5 +250,15 @@ DRL_API int drl_apex_td_dh(const float* q_on, const float* q_tg, int B, int A, c
     k_apex_td_dh<<<(B + 15) / 16, 1024, 0, s>>>(q_on, q_tg, B, A, idx, act, rew, done, p_sampled, (StepState*)st, gamma_n, alpha,
                                                prio_eps, n_scale, dq, new_prio, (const bf16_t*)h, (const bf16_t*)w_adv,
                                                (const bf16_t*)w_val, (bf16_t*)dh);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_head_fwd_dual(const void* h1, int M1, const void* w_adv1, const float* b_adv1, const void* w_val1, const float* b_val1,
+                              float* q1, const void* h2, int M2, const void* w_adv2, const float* b_adv2, const void* w_val2,
+                              const float* b_val2, float* q2, int A, hipStream_t s) {
+    if (M1 <= 0 || M2 <= 0 || A <= 0 || A > MAX_A) return -1;
+    const HeadNet n1{(const bf16_t*)h1, (const bf16_t*)w_adv1, b_adv1, (const bf16_t*)w_val1, b_val1, q1, M1};
+    const HeadNet n2{(const bf16_t*)h2, (const bf16_t*)w_adv2, b_adv2, (const bf16_t*)w_val2, b_val2, q2, M2};
+    k_head_fwd_dual<<<(M1 + M2 + 3) / 4, 256, 0, s>>>(n1, n2, A);
     return (int)hipGetLastError();
 }

@@ -55,6 +55,21 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
                eps, eps_mod, seed, ctr)
 
 
+def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
+                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers) -> None:
+    """Forward of TWO networks (online on n1 frames, target on n2 frames), 5 launches in total: each layer of both networks
+    is one launch, so the learner's step needs no second stream (no fork / join) for the target network."""
+    H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
+                    wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
+    for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
+        H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
+                        getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst))
+    H.gemm_nt_dual(b1.act3, wb1.view("fc1.w"), wf1.view("fc1.b"), b1.h, b2.act3, wb2.view("fc1.w"), wf2.view("fc1.b"), b2.h,
+                   1024, 3136, flags=H.EPI_RELU)
+    H.head_fwd_dual(b1.h, wb1.view("adv2.w"), wf1.view("adv2.b"), wb1.view("val2.w"), wf1.view("val2.b"), b1.q,
+                    b2.h, wb2.view("adv2.w"), wf2.view("adv2.b"), wb2.view("val2.w"), wf2.view("val2.b"), b2.q)
+
+
 class ApexEngine:
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
@@ -101,6 +116,7 @@ class ApexEngine:
         self.presample = self.fused_bwd and B % 4 == 0 and _os.environ.get("DRL_PRESAMPLE", "1") != "0"
         if self.presample:
             replay._next_buffers()                                        # allocate now, never inside a graph capture
+        self.dual_fwd = _os.environ.get("DRL_DUAL_FWD", "1") != "0"       # online + target forward as one launch per layer
         self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
@@ -149,10 +165,13 @@ class ApexEngine:
         # presample: from the second step on the batch was already drawn by the previous step's optimizer launch.
         if not (self.presample and self._primed):
             r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
-        with self._fork(0):                                        # target net on s' || online net on [s ; s']
-            torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
-        torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
-        self._join()
+        if self.dual_fwd:
+            torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg)
+        else:
+            with self._fork(0):                                    # target net on s' || online net on [s ; s']
+                torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
+            torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
+            self._join()
         G, Pb, on = self.G, self.Pb, self.on
         if not self.fused_bwd:
             H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,

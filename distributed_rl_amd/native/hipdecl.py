@@ -27,10 +27,14 @@ SIGS = {
     # head.hip
     "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],
     "drl_head_bwd": [P, P, I, I, P, P, P, P, P, P, P, I, P],
+    "drl_head_fwd_dual": [P, I, P, P, P, P, P, P, I, P, P, P, P, P, I, P],
     # gemm.hip
     "drl_gemm": [I, I, P, L, P, L, I, I, I, P, L, P, P, L, F, I, I, P],
     "drl_conv_fwd": [I, P, P, I, P, P, P, I, P],
     "drl_conv_wgrad": [I, P, P, I, P, P, I, P],
+    "drl_conv_fwd_dual": [I, P, I, P, P, P, P, I, P, P, P, P],
+    "drl_gemm_nt_dual": [P, I, P, P, P, P, I, P, P, P, I, I, I, P],
+    "drl_conv1_fwd_dual": [P, P, I, P, P, P, P, I, P, P, P, P],
     # conv_direct.hip
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],

@@ -277,6 +277,41 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
                                   (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
 
 
+def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None) -> None:
+    """Forward of one conv layer (+bias+ReLU) of TWO networks in one launch (Ape-X learner: online net on [s ; s'] and
+    target net on s'). layer 1: x1 is the frame store, x2 is ignored, the two nets gather through frame_off1 / frame_off2."""
+    for w, b, o in ((w1, b1, out1), (w2, b2, out2)):
+        _chk(w, torch.bfloat16, "w"); _chk(b, torch.float32, "bias"); _chk(o, torch.bfloat16, "out")
+    if layer == 1:
+        _chk(x1, torch.uint8, "x")
+        _ck(native.hip().drl_conv1_fwd_dual(_p(x1), _p(frame_off1), f1, _p(w1), _p(b1), _p(out1), _p(frame_off2), f2, _p(w2),
+                                            _p(b2), _p(out2), _s()), "conv1_fwd_dual")
+        return
+    _chk(x1, torch.bfloat16, "x1"); _chk(x2, torch.bfloat16, "x2")
+    _ck(native.hip().drl_conv_fwd_dual(layer, _p(x1), f1, _p(w1), _p(b1), _p(out1), _p(x2), f2, _p(w2), _p(b2), _p(out2), _s()),
+        "conv_fwd_dual")
+
+
+def gemm_nt_dual(a1, w1, b1, c1, a2, w2, b2, c2, N: int, K: int, flags: int = 0) -> None:
+    """c_i = epi(a_i[M_i,K] . w_i[N,K]^T + b_i) for two (a, w, b, c) sets in one launch (64x64 LDS-DMA tiles)."""
+    for a, w, c in ((a1, w1, c1), (a2, w2, c2)):
+        _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w")
+        _chk(c, torch.float32 if flags & EPI_OUT_F32 else torch.bfloat16, "c")
+        assert a.shape[-1] == K and w.shape == (N, K) and c.shape == (a.shape[0], N)
+    _ck(native.hip().drl_gemm_nt_dual(_p(a1), a1.shape[0], _p(w1), _p(b1), _p(c1), _p(a2), a2.shape[0], _p(w2), _p(b2), _p(c2),
+                                      N, K, flags, _s()), "gemm_nt_dual")
+
+
+def head_fwd_dual(h1, wa1, ba1, wv1, bv1, q1, h2, wa2, ba2, wv2, bv2, q2) -> None:
+    """Dueling head (Q values only) of two networks in one launch."""
+    (M1, A), (M2, A2) = q1.shape, q2.shape
+    assert A == A2 and h1.shape == (M1, 1024) and h2.shape == (M2, 1024) and wa1.shape == (A, 512) and wa2.shape == (A, 512)
+    for h, q in ((h1, q1), (h2, q2)):
+        _chk(h, torch.bfloat16, "h"); _chk(q, torch.float32, "q")
+    _ck(native.hip().drl_head_fwd_dual(_p(h1), M1, _p(wa1), _p(ba1), _p(wv1), _p(bv1), _p(q1), _p(h2), M2, _p(wa2), _p(ba2),
+                                       _p(wv2), _p(bv2), _p(q2), A, _s()), "head_fwd_dual")
+
+
 def conv_wgrad(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, frames: int,
                frame_off: Optional[torch.Tensor] = None, splits: int = 64) -> None:
     _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw")

@@ -465,6 +465,56 @@ def test_conv1_frame_offsets(hip):
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("f1,f2", [(5, 3), (64, 32), (130, 65)])
+def test_conv_fwd_dual(hip, layer, f1, f2):
+    """Two networks per launch (online + target) against the fp32 convolution of each."""
+    H = hip
+    x1, xf1, w1, b1, (cin, cout, ks, s, hw) = _conv_setup(layer, f1, layer * 31 + f1)
+    x2, xf2, w2, b2, _ = _conv_setup(layer, f2, layer * 37 + f2)
+    oh = (hw - ks) // s + 1
+    o1 = torch.zeros(f1, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.zeros(f2, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
+    if layer == 1:
+        store = torch.cat([x1, x2]).to(DEV)
+        off1 = (torch.arange(f1) * 28224).to(DEV)
+        off2 = ((f1 + torch.arange(f2)) * 28224).to(DEV)
+        H.conv_fwd_dual(1, store, f1, w1.to(DEV), b1.to(DEV), o1, None, f2, w2.to(DEV), b2.to(DEV), o2,
+                        frame_off1=off1, frame_off2=off2)
+    else:
+        H.conv_fwd_dual(layer, x1.to(DEV), f1, w1.to(DEV), b1.to(DEV), o1, x2.to(DEV), f2, w2.to(DEV), b2.to(DEV), o2)
+    for o, xf, w, b in ((o1, xf1, w1, b1), (o2, xf2, w2, b2)):
+        ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, stride=s)).permute(0, 2, 3, 1)
+        torch.testing.assert_close(o.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M1,M2", [(7, 3), (128, 64), (1024, 512)])
+def test_gemm_nt_and_head_dual(hip, M1, M2):
+    H = hip
+    g = torch.Generator().manual_seed(M1)
+    A = 6
+    outs = []
+    nets = []
+    for M in (M1, M2):
+        a = bf(torch.relu(torch.randn(M, 3136, generator=g)))
+        w = bf(torch.randn(1024, 3136, generator=g) * 0.02)
+        b = torch.randn(1024, generator=g)
+        wa, wv = bf(torch.randn(A, 512, generator=g) * 0.05), bf(torch.randn(1, 512, generator=g) * 0.05)
+        ba, bv = torch.randn(A, generator=g), torch.randn(1, generator=g)
+        nets.append((a, w, b, wa, ba, wv, bv))
+        outs.append((torch.zeros(M, 1024, dtype=torch.bfloat16, device=DEV), torch.zeros(M, A, device=DEV)))
+    d = [[t.to(DEV) for t in n] for n in nets]
+    H.gemm_nt_dual(d[0][0], d[0][1], d[0][2], outs[0][0], d[1][0], d[1][1], d[1][2], outs[1][0], 1024, 3136, flags=H.EPI_RELU)
+    H.head_fwd_dual(outs[0][0], d[0][3], d[0][4], d[0][5], d[0][6], outs[0][1],
+                    outs[1][0], d[1][3], d[1][4], d[1][5], d[1][6], outs[1][1])
+    for (a, w, b, wa, ba, wv, bv), (h, q) in zip(nets, outs):
+        h_ref = torch.relu(a.float() @ w.float().t() + b)
+        torch.testing.assert_close(h.float().cpu(), h_ref, rtol=2e-2, atol=2e-2)
+        hf = h.float().cpu()
+        q_ref = oracle.dueling_combine(hf[:, 512:] @ wv.float().t() + bv, hf[:, :512] @ wa.float().t() + ba)
+        torch.testing.assert_close(q.cpu(), q_ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("frames,splits", [(3, 1), (64, 16)])
 def test_conv_wgrad_and_bias(hip, layer, frames, splits):
     H = hip
