@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--actor-envs", type=int, default=4096)
     args = ap.parse_args()
 
+    wd = float(os.environ.get("DRL_BENCH_WATCHDOG", "0"))
+    if wd > 0:                               # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     import torch
     from distributed_rl_amd.config import ApexConfig
     from distributed_rl_amd.parallel.dist import Dist
@@ -96,6 +100,8 @@ def main():
     st = eng.stats()
     extra = {"apex_updates_per_s": updates_s, "loss": st["loss"], "grad_norm": st["grad_norm"],
              "replay_items_per_gpu": cap, "graph": eng._graphs[0] if eng._graphs else "eager"}
+    if dist.world_size > 1:
+        extra["grad_all_reduce"] = "direct xGMI kernel (in graph)" if dist.xgmi is not None else "RCCL"
 
     # side metrics only on one GPU: at N > 1 nothing after the timed region may put the headline line at risk
     if not args.no_extra and dist.world_size == 1:

@@ -87,7 +87,8 @@ class ApexEngine:
         self.Pb = self.P.like(torch.bfloat16)           # bf16 shadow read by the MFMA kernels
         self.T = self.P.like()                          # target fp32 (biases) ...
         self.Tb = self.P.like(torch.bfloat16)           # ... and bf16
-        self.G = self.P.like()                          # flat gradient
+        # flat gradient; multi-GPU: the direct xGMI all-reduce's communication buffer when that path is usable
+        self.G = self.P.like(flat=dist.grad_buffer(lay.total) if hasattr(dist, "grad_buffer") else None)
         self.SQ = self.P.like()                         # RMSprop second moment
         H.cast_bf16(self.P.flat, self.Pb.flat)
         self.sync_target()
@@ -276,9 +277,9 @@ class ApexEngine:
         two collectives per step, never per-tensor buckets."""
         cut = self._grad_cut
         head()
-        w_big = self.dist.all_reduce_async(self.G.flat[cut:])
+        w_big = self.dist.all_reduce_async(self.G.flat[cut:], channel=0)
         torso()
-        w_small = self.dist.all_reduce_async(self.G.flat[:cut])
+        w_small = self.dist.all_reduce_async(self.G.flat[:cut], channel=1)
         w_big.wait()
         w_small.wait()
         optimize()
@@ -347,6 +348,8 @@ class ApexEngine:
 
     # ---- host-visible state ---------------------------------------------------------------------------
     def stats(self) -> dict:
+        if getattr(self.dist, "xgmi", None) is not None:
+            self.dist.check_health()                     # a timed-out poll of the direct all-reduce must not go unnoticed
         return H.read_step_state(self.st)
 
     def state_dict(self):

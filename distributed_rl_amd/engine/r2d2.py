@@ -129,7 +129,7 @@ class R2D2Engine:
         self.Pb = self.P.like(torch.bfloat16)
         self.Tg = self.P.like()
         self.Tb = self.P.like(torch.bfloat16)
-        self.G = self.P.like()
+        self.G = self.P.like(flat=dist.grad_buffer(lay.total) if hasattr(dist, "grad_buffer") else None)
         self.M1 = self.P.like()
         self.M2 = self.P.like()
         H.cast_bf16(self.P.flat, self.Pb.flat)
@@ -400,6 +400,8 @@ class R2D2Engine:
             self.sync_target()
 
     def stats(self) -> dict:
+        if getattr(self.dist, "xgmi", None) is not None:
+            self.dist.check_health()
         st = H.read_step_state(self.st)
         if self.persistent_lstm and (int(self.on.err[0].item()) or int(self.tg.err[0].item())):
             raise RuntimeError("persistent LSTM kernel: an inter-workgroup wait timed out (results invalid); "

@@ -184,9 +184,13 @@ def layout_for(model) -> Layout:
 class ParamPack:
     """A flat buffer (any dtype/device) laid out by a :class:`Layout`, with named views."""
 
-    def __init__(self, layout: Layout, device="cpu", dtype=torch.float32):
+    def __init__(self, layout: Layout, device="cpu", dtype=torch.float32, flat: torch.Tensor = None):
         self.layout = layout
-        self.flat = torch.zeros(layout.total, device=device, dtype=dtype)
+        if flat is not None:                                   # adopt an existing buffer (e.g. a communication buffer)
+            assert flat.numel() == layout.total and flat.is_contiguous()
+            self.flat = flat
+        else:
+            self.flat = torch.zeros(layout.total, device=device, dtype=dtype)
 
     def view(self, name: str) -> torch.Tensor:
         s = self.layout.segments[name]
@@ -195,8 +199,8 @@ class ParamPack:
     def views(self) -> Dict[str, torch.Tensor]:
         return {n: self.view(n) for n in self.layout.segments}
 
-    def like(self, dtype=None) -> "ParamPack":
-        return ParamPack(self.layout, self.flat.device, dtype or self.flat.dtype)
+    def like(self, dtype=None, flat: torch.Tensor = None) -> "ParamPack":
+        return ParamPack(self.layout, self.flat.device, dtype or self.flat.dtype, flat=flat)
 
     @torch.no_grad()
     def load_state_dict(self, sd) -> None:

@@ -1,5 +1,5 @@
 """ctypes signatures of libdrl_hip.so (csrc/hip/*.hip). Every entry point returns a hipError_t-style int."""
-from ctypes import c_float, c_int, c_longlong, c_ulonglong, c_void_p, POINTER
+from ctypes import c_double, c_float, c_int, c_longlong, c_ulonglong, c_void_p, POINTER
 
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 LP = POINTER(c_longlong)
@@ -54,6 +54,14 @@ SIGS = {
     "drl_col2im": [I, P, P, P, I, P],
     "drl_colsum": [P, I, I, P, P],
     "drl_relu_mask": [P, P, P, L, P],
+    # xgmi_ar.hip
+    "drl_xar_create": [I, I, L, I, c_double, POINTER(c_void_p)],
+    "drl_xar_handles": [P, P],
+    "drl_xar_open": [P, I, P, I],
+    "drl_xar_all_reduce": [P, L, L, I, P],
+    "drl_xar_error": [P],
+    "drl_xar_set_timeout": [P, c_double],
+    "drl_xar_destroy": [P],
 }
 
 
@@ -64,3 +72,6 @@ def declare(lib) -> None:
         fn = getattr(lib, name)
         fn.restype = c_int
         fn.argtypes = args
+    if hasattr(lib, "drl_xar_data_ptr"):
+        lib.drl_xar_data_ptr.restype = c_void_p
+        lib.drl_xar_data_ptr.argtypes = [c_void_p]

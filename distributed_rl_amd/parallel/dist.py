@@ -25,6 +25,17 @@ class _Done:
         return True
 
 
+class _StreamWork:
+    """Handle of a collective that runs as a kernel on a side stream: ``wait()`` orders the current stream after it."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return True
+
+
 class Dist:
     def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: int = 600):
         import datetime
@@ -32,13 +43,20 @@ class Dist:
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if device is None:
-            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+            if torch.cuda.is_available():
+                # DRL_SHARE_GPU=1: rehearse W ranks on fewer GPUs (ranks share devices round-robin; RCCL refuses that, so
+                # combine it with DRL_DIST_BACKEND=gloo)
+                n = torch.cuda.device_count() if os.environ.get("DRL_SHARE_GPU") == "1" else 1 << 30
+                device = torch.device("cuda", self.local_rank % n)
+            else:
+                device = torch.device("cpu")
         self.device = device
         if device.type == "cuda":
             torch.cuda.set_device(device)
-        self.backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        self.backend = backend or os.environ.get("DRL_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         # DRL_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
         self.enabled = self.world_size > 1 or os.environ.get("DRL_FORCE_DIST") == "1"
+        self.xgmi = None                                       # direct xGMI all-reduce, see grad_buffer()
         if self.enabled and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -48,17 +66,108 @@ class Dist:
             td.init_process_group(self.backend, rank=self.rank, world_size=self.world_size,
                                   timeout=datetime.timedelta(seconds=timeout_s), **kw)
 
+    # ---- direct xGMI all-reduce (parallel/xgmi.py) -----------------------------------------------------------
+    def grad_buffer(self, numel: int) -> Optional[torch.Tensor]:
+        """Flat fp32 gradient buffer for an engine. On a multi-GPU node this is the communication buffer of the direct
+        xGMI all-reduce (every peer maps it; the collective is one in-place kernel on it, csrc/hip/xgmi_ar.hip) - when that
+        path is available AND has just reproduced RCCL's result on this very set of GPUs; otherwise ``None`` (the
+        engine allocates an ordinary tensor and the collectives go through RCCL).
+
+        ``DRL_XGMI_AR`` = 0: never; 1: required (failures raise); unset / "auto": try, verify, fall back. Collective call:
+        every rank must make it at the same point."""
+        mode = os.environ.get("DRL_XGMI_AR", "auto")
+        usable = (self.enabled and mode != "0" and self.device.type == "cuda" and 2 <= self.world_size <= 8
+                  and self.xgmi is None)
+        if not usable:
+            return None
+        ar, why = None, ""
+        try:
+            import socket
+            hosts = [None] * self.world_size
+            td.all_gather_object(hosts, socket.gethostname())
+            if len(set(hosts)) != 1:
+                raise RuntimeError("ranks on different hosts")
+            from .xgmi import XgmiAllReduce
+            ar = XgmiAllReduce(numel, self.device, self.rank, self.world_size,
+                               n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")))
+            ok = self._verify_xgmi(ar, numel)
+        except Exception as e:                                  # noqa: BLE001 - any failure means "use RCCL"
+            ok, why = False, repr(e)
+        try:                                                    # same verdict on every rank
+            v = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            td.all_reduce(v, op=td.ReduceOp.MIN)
+            ok = float(v.item()) > 0.5
+        except Exception as e:                                  # noqa: BLE001
+            ok, why = False, why or repr(e)
+        if not ok:
+            if ar is not None:
+                try:
+                    ar.close()
+                except Exception:                               # noqa: BLE001
+                    pass
+            if mode == "1":
+                raise RuntimeError("DRL_XGMI_AR=1 but the direct xGMI all-reduce is not usable: %s" % (why or "mismatch"))
+            if self.rank == 0:
+                print("[dist] direct xGMI all-reduce not used (%s); gradients go through RCCL" % (why or "verification failed"),
+                      flush=True)
+            return None
+        self.xgmi = ar
+        self._xgmi_stream = torch.cuda.Stream(self.device)
+        ar.flat.zero_()
+        return ar.flat[:numel]
+
+    def _verify_xgmi(self, ar, numel: int) -> bool:
+        """The kernel against RCCL on rank-dependent random data: whole buffer, an engine-like split on two channels, a
+        captured + replayed launch. Any mismatch or timed-out poll rejects the path."""
+        g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
+        cut = (numel // 41) // 64 * 64
+        ar.set_timeout(1.0)                                     # a broken path must fail fast, not look like a hang
+        for k in range(3):
+            ar.flat.zero_()
+            ar.flat[:numel].normal_(generator=g)
+            want = ar.flat.clone()
+            td.all_reduce(want, op=td.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
+            if k == 0:
+                ar.all_reduce(ar.flat[:numel], channel=0)
+            else:
+                ar.all_reduce(ar.flat[cut:numel], channel=0)
+                ar.all_reduce(ar.flat[:cut], channel=1)
+            torch.cuda.synchronize(self.device)
+            if ar.error() != 0 or not torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4):
+                return False
+        ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "20")))
+        return True
+
+    def check_health(self) -> None:
+        """Raises if a poll of the direct all-reduce timed out since the last call (a peer did not arrive). Synchronises."""
+        if self.xgmi is not None:
+            e = self.xgmi.error()
+            if e:
+                raise RuntimeError("direct xGMI all-reduce: barrier %d timed out on rank %d" % (e - 1, self.rank))
+
     # ---- collectives --------------------------------------------------------------------------------
     def all_reduce_flat(self, flat: torch.Tensor) -> None:
         """SUM over ranks, in place, one collective for the whole gradient."""
-        if self.enabled:
-            td.all_reduce(flat, op=td.ReduceOp.SUM)
+        if not self.enabled:
+            return
+        if self.xgmi is not None and self.xgmi.owns(flat):
+            self.xgmi.all_reduce(flat, channel=0)
+            return
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
 
-    def all_reduce_async(self, flat: torch.Tensor):
-        """SUM over ranks, in place, asynchronous: the collective runs on the backend's own stream after the work
-        already queued on the current stream; ``.wait()`` on the returned handle orders the current stream after it."""
+    def all_reduce_async(self, flat: torch.Tensor, channel: int = 0):
+        """SUM over ranks, in place, asynchronous: the collective runs on a side stream (RCCL's own, or ours for the
+        direct xGMI kernel) after the work already queued on the current stream; ``.wait()`` on the returned handle
+        orders the current stream after it. Collectives that may be in flight together use different channels."""
         if not self.enabled:
             return _Done()
+        if self.xgmi is not None and self.xgmi.owns(flat):
+            side = self._xgmi_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.xgmi.all_reduce(flat, channel=channel)
+            return _StreamWork(side)
         return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self, module: torch.nn.Module) -> None:
@@ -83,6 +192,8 @@ class Dist:
         decides once: a small all-reduce is captured, replayed twice and checked on every rank, and the ranks agree
         on the verdict (MIN) so that all of them build the same kind of step."""
         env = os.environ.get("DRL_GRAPH_COLLECTIVES")
+        if self.xgmi is not None and env != "0":
+            return True                                        # the direct all-reduce is an ordinary kernel launch
         if env in ("0", "1"):
             return env == "1"
         if getattr(self, "_graph_ok", None) is None:
@@ -161,5 +272,8 @@ class Dist:
                 td.barrier()
 
     def close(self) -> None:
+        if self.xgmi is not None:
+            self.xgmi.close()
+            self.xgmi = None
         if self.enabled and td.is_initialized():
             td.destroy_process_group()

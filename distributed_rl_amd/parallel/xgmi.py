@@ -1,0 +1,102 @@
+"""Direct all-reduce over the xGMI mesh (csrc/hip/xgmi_ar.hip).
+
+The reference has no gradient collective at all (single learner, ape_x/learner.py:11); SURVEY M7 asks for a
+latency-optimal one: the gradients (13-32 MB) are small, an MI355X node is a full mesh, so every GPU exchanges 1/W of the
+buffer with each of its peers at once instead of walking a ring. :class:`XgmiAllReduce` owns the gradient buffer (the
+engines build their flat gradient ``ParamPack`` on top of it), exchanges the IPC handles over an existing
+``torch.distributed`` group once, and afterwards a collective is ONE kernel launch on the caller's stream - it is
+captured into the step's hipGraph like any compute kernel.
+
+Every rank must call :meth:`all_reduce` with the same arguments in the same order per channel; collectives that may be in
+flight at the same time (the engines' big FC slice under the conv backward, then the small conv slice) use different
+channels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as td
+
+from .. import native
+
+N_CHANNELS = 4
+MAX_WORLD = 8
+
+
+class _DevMem:
+    """Zero-copy view of a raw device pointer for ``torch.as_tensor`` (CUDA array interface, version 2)."""
+
+    def __init__(self, ptr: int, numel: int, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2,
+                                         "strides": None}
+
+
+class XgmiAllReduce:
+    def __init__(self, numel: int, device: torch.device, rank: int, world: int, group=None, n_blocks: int = 32,
+                 timeout_s: float = 20.0):
+        if world > MAX_WORLD:
+            raise ValueError("xGMI all-reduce: at most %d ranks (one node)" % MAX_WORLD)
+        self.lib = native.hip()
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.rank, self.world, self.device = rank, world, device
+        self.cap = (numel + 63) // 64 * 64
+        self._ctx = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.drl_xar_create(rank, world, self.cap, n_blocks, timeout_s, ctypes.byref(self._ctx)), "create")
+            mine = ctypes.create_string_buffer(128)
+            self._ck(self.lib.drl_xar_handles(self._ctx, mine), "handles")
+            every = [None] * world
+            # the peer's device ordinal is only meaningful when both processes enumerate the same devices
+            vis = os.environ.get("HIP_VISIBLE_DEVICES", "") + "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "")
+            if world > 1:
+                td.all_gather_object(every, (bytes(mine.raw), self.device.index, vis), group=group)
+            for p in range(world):
+                if p != rank:
+                    handles, dev_p, vis_p = every[p]
+                    self._ck(self.lib.drl_xar_open(self._ctx, p, ctypes.c_char_p(handles), dev_p if vis_p == vis else -1),
+                             "open(peer %d)" % p)
+            ptr = self.lib.drl_xar_data_ptr(self._ctx)
+            self.flat = torch.as_tensor(_DevMem(ptr, self.cap, self), device=self.device)
+        assert self.flat.data_ptr() == ptr and self.flat.dtype == torch.float32
+        self._base = ptr
+        if world > 1:
+            td.barrier(group=group)                      # nobody launches before every peer has mapped every buffer
+
+    def _ck(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError("xgmi all-reduce %s failed: error %d" % (what, rc))
+
+    def owns(self, t: torch.Tensor) -> bool:
+        a = t.data_ptr()
+        return (t.dtype == torch.float32 and t.is_contiguous() and self._base <= a
+                and a + t.numel() * 4 <= self._base + self.cap * 4)
+
+    def all_reduce(self, t: torch.Tensor, channel: int = 0) -> None:
+        """In-place SUM over ranks of ``t`` (a contiguous slice of ``self.flat`` starting at a multiple of 4 elements), on
+        the current stream."""
+        assert self.owns(t), "tensor is not a slice of the xGMI communication buffer"
+        off = (t.data_ptr() - self._base) // 4
+        n = min((t.numel() + 3) // 4 * 4, self.cap - off)       # the padding is zero on every rank
+        self._ck(self.lib.drl_xar_all_reduce(self._ctx, off, n, channel, torch.cuda.current_stream(self.device).cuda_stream),
+                 "launch")
+
+    def set_timeout(self, seconds: float) -> None:
+        """Bound of every flag poll inside the kernel (launches issued after this call)."""
+        self._ck(self.lib.drl_xar_set_timeout(self._ctx, float(seconds)), "set_timeout")
+
+    def error(self) -> int:
+        """0 = fine; otherwise the barrier (1..3) whose poll timed out. Synchronises the device."""
+        with torch.cuda.device(self.device):
+            return int(self.lib.drl_xar_error(self._ctx))
+
+    def close(self) -> None:
+        if self._ctx:
+            with torch.cuda.device(self.device):
+                self.lib.drl_xar_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()

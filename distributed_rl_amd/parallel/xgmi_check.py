@@ -1,0 +1,135 @@
+"""Self-check / micro-benchmark of the direct xGMI all-reduce; one process per rank:
+
+    RANK=r WORLD_SIZE=W MASTER_ADDR=127.0.0.1 MASTER_PORT=p python -m distributed_rl_amd.parallel.xgmi_check [--numel N]
+
+Ranks share GPUs round-robin when there are fewer GPUs than ranks (a 1-GPU box runs W ranks on one device: the IPC
+mapping, the flag protocol and graph replay are exercised, the links are not). The handles travel over a gloo group, the
+expected sums are computed on the host. Prints one JSON line per rank; exit code 0 = every comparison passed."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as td
+
+
+def engine_check() -> int:
+    """W data-parallel Ape-X learners (one process each) whose step graph contains the direct all-reduce: parameters must
+    stay bit-identical across ranks (every slice is reduced by exactly one rank and copied by the others)."""
+    from distributed_rl_amd.config import ApexConfig
+    from distributed_rl_amd.engine.apex import ApexEngine
+    from distributed_rl_amd.parallel.dist import Dist
+    from distributed_rl_amd.replay.device_per import DevicePER
+    os.environ.setdefault("DRL_DIST_BACKEND", "gloo")
+    os.environ.setdefault("DRL_SHARE_GPU", "1")
+    os.environ.setdefault("LOCAL_RANK", os.environ["RANK"])
+    os.environ["DRL_XGMI_AR"] = "1"                               # required: a failure raises instead of falling back
+    dist = Dist()
+    B, cap = 32, 4096
+    cfg = ApexConfig(batch_size=B, target_update=10 ** 9)
+    rep = DevicePER(cap, dist.device, batch_size=B, seed=7 + dist.rank)
+    rep.fill_synthetic(cap - 64, n_action=4, seed=dist.rank)       # every rank owns a different shard
+    torch.manual_seed(0)
+    eng = ApexEngine(4, cfg, rep, dist.device, dist=dist, use_graph=True)
+    assert dist.xgmi is not None and dist.xgmi.owns(eng.G.flat)
+    p0 = eng.P.flat.clone()
+    losses = []
+    for _ in range(12):
+        eng.step()
+        losses.append(eng.stats()["loss"])
+    torch.cuda.synchronize()
+    mine = eng.P.flat.cpu()
+    every = [None] * dist.world_size
+    td.all_gather_object(every, (float(mine.double().sum()), float(mine.abs().double().sum()), eng._graphs[0]))
+    ok = all(e == every[0] for e in every) and bool(torch.isfinite(mine).all()) and not torch.equal(mine, p0.cpu())
+    ok = ok and every[0][2] == "one" and all(l == l for l in losses)
+    print(json.dumps({"rank": dist.rank, "ok": ok, "sums": every[0][:2], "graph": every[0][2], "loss": losses[-1]}), flush=True)
+    dist.barrier()
+    dist.close()
+    return 0 if ok else 1
+
+
+def main() -> int:
+    if "--engine" in sys.argv:
+        return engine_check()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--numel", type=int, default=3293184)         # Ape-X flat gradient (A = 4), 13.2 MB
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--bench", type=int, default=0)
+    ap.add_argument("--blocks", type=int, default=32)
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from distributed_rl_amd.parallel.xgmi import XgmiAllReduce
+    ar = XgmiAllReduce(a.numel, dev, rank, world, n_blocks=a.blocks)
+    res = {"rank": rank, "world": world, "device": str(dev), "numel": a.numel, "checks": 0, "max_err": 0.0}
+    ok = True
+    g = torch.Generator().manual_seed(100 + rank)
+    cut = (a.numel // 41) // 64 * 64                               # an engine-like (small slice | big slice) split
+    cases = [(0, a.numel, 0), (cut, a.numel - cut, 0), (0, cut, 1), (64, 4, 2), (0, a.numel - 3, 3)]
+    for it in range(a.iters):
+        for off, n, ch in cases:
+            x = torch.randn(ar.cap, generator=g)
+            x[a.numel:] = 0                                        # the padding stays zero, as in the engines
+            ar.flat.copy_(x)
+            torch.cuda.synchronize()
+            td.barrier()                                           # (the engines order this by the step itself)
+            ar.all_reduce(ar.flat[off:off + n], channel=ch)
+            got = ar.flat.cpu()
+            want = x.clone()
+            n_pad = min((n + 3) // 4 * 4, ar.cap - off)
+            part = x[off:off + n_pad].clone()
+            td.all_reduce(part)
+            want[off:off + n_pad] = part
+            err = float((got - want).abs().max())
+            res["max_err"] = max(res["max_err"], err)
+            res["checks"] += 1
+            if not err < 1e-4 * (world ** 0.5):
+                ok = False
+            td.barrier()
+    # back-to-back collectives on two channels inside a replayed graph (what the engines do)
+    s = torch.cuda.Stream(dev)
+    x = torch.full((ar.cap,), float(rank + 1))
+    x[a.numel:] = 0
+    stage = x.to(dev)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        ar.flat.copy_(stage)
+        torch.cuda.synchronize()
+        td.barrier()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            ar.flat.copy_(stage)
+            ar.all_reduce(ar.flat[cut:a.numel], channel=0)
+            ar.all_reduce(ar.flat[:cut], channel=1)
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+    tot = float(sum(range(1, world + 1)))
+    ok = ok and bool((ar.flat[:a.numel] == tot).all())
+    res["graph_ok"] = bool((ar.flat[:a.numel] == tot).all())
+    if a.bench:
+        td.barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s):
+            for _ in range(a.bench):
+                ar.all_reduce(ar.flat[:a.numel], channel=2)
+            torch.cuda.synchronize()
+        res["us_per_all_reduce"] = (time.perf_counter() - t0) / a.bench * 1e6
+    res["error_flag"] = ar.error()
+    ok = ok and res["error_flag"] == 0
+    res["ok"] = ok
+    td.barrier()
+    print(json.dumps(res), flush=True)
+    ar.close()
+    td.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
