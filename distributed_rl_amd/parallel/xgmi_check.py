@@ -17,24 +17,35 @@ import torch
 import torch.distributed as td
 
 
-def engine_check() -> int:
-    """W data-parallel Ape-X learners (one process each) whose step graph contains the direct all-reduce: parameters must
-    stay bit-identical across ranks (every slice is reduced by exactly one rank and copied by the others)."""
-    from distributed_rl_amd.config import ApexConfig
-    from distributed_rl_amd.engine.apex import ApexEngine
+def engine_check(r2d2: bool) -> int:
+    """W data-parallel learners (one process each) whose step graph contains the direct all-reduce: parameters must stay
+    bit-identical across ranks (every slice is reduced by exactly one rank and copied by the others)."""
     from distributed_rl_amd.parallel.dist import Dist
-    from distributed_rl_amd.replay.device_per import DevicePER
     os.environ.setdefault("DRL_DIST_BACKEND", "gloo")
     os.environ.setdefault("DRL_SHARE_GPU", "1")
     os.environ.setdefault("LOCAL_RANK", os.environ["RANK"])
     os.environ["DRL_XGMI_AR"] = "1"                               # required: a failure raises instead of falling back
     dist = Dist()
-    B, cap = 32, 4096
-    cfg = ApexConfig(batch_size=B, target_update=10 ** 9)
-    rep = DevicePER(cap, dist.device, batch_size=B, seed=7 + dist.rank)
-    rep.fill_synthetic(cap - 64, n_action=4, seed=dist.rank)       # every rank owns a different shard
-    torch.manual_seed(0)
-    eng = ApexEngine(4, cfg, rep, dist.device, dist=dist, use_graph=True)
+    torch.manual_seed(0)                                          # same initial weights on every rank
+    if r2d2:
+        from distributed_rl_amd.config import R2D2Config
+        from distributed_rl_amd.engine.r2d2 import R2D2Engine
+        from distributed_rl_amd.replay.device_seq import DeviceSequenceReplay
+        # ranks share one GPU here: two grid-wide persistent recurrences cannot be co-resident, use the per-step launches
+        os.environ.setdefault("DRL_PERSISTENT_LSTM", "0")
+        cfg = R2D2Config(batch_size=8, burn_in=4, seq_len=8, nstep=2, target_update=10 ** 9)
+        rep = DeviceSequenceReplay(40, dist.device, cfg, seed=5 + dist.rank)
+        rep.fill_synthetic(40, n_action=4, seed=dist.rank)         # every rank owns a different shard
+        eng = R2D2Engine(4, cfg, rep, dist.device, dist=dist, use_graph=True)
+    else:
+        from distributed_rl_amd.config import ApexConfig
+        from distributed_rl_amd.engine.apex import ApexEngine
+        from distributed_rl_amd.replay.device_per import DevicePER
+        B, cap = 32, 4096
+        cfg = ApexConfig(batch_size=B, target_update=10 ** 9)
+        rep = DevicePER(cap, dist.device, batch_size=B, seed=7 + dist.rank)
+        rep.fill_synthetic(cap - 64, n_action=4, seed=dist.rank)
+        eng = ApexEngine(4, cfg, rep, dist.device, dist=dist, use_graph=True)
     assert dist.xgmi is not None and dist.xgmi.owns(eng.G.flat)
     p0 = eng.P.flat.clone()
     losses = []
@@ -54,8 +65,8 @@ def engine_check() -> int:
 
 
 def main() -> int:
-    if "--engine" in sys.argv:
-        return engine_check()
+    if "--engine" in sys.argv or "--engine-r2d2" in sys.argv:
+        return engine_check("--engine-r2d2" in sys.argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--numel", type=int, default=3293184)         # Ape-X flat gradient (A = 4), 13.2 MB
     ap.add_argument("--iters", type=int, default=5)

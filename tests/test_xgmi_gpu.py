@@ -52,9 +52,10 @@ def test_xgmi_all_reduce_processes(world):
         assert res["ok"] and res["graph_ok"] and res["error_flag"] == 0 and res["checks"] == 10
 
 
-def test_apex_engine_data_parallel_over_direct_all_reduce():
-    """Two learner processes, sharded replay, the all-reduce kernels captured in the one-graph step: identical
-    parameters on both ranks after 12 updates."""
-    res = _run_ranks(2, ["--engine"])
+@pytest.mark.parametrize("flag", ["--engine", "--engine-r2d2"])
+def test_engine_data_parallel_over_direct_all_reduce(flag):
+    """Two learner processes (Ape-X / R2D2), sharded replay, the all-reduce kernels captured in the one-graph step:
+    identical parameters on both ranks after 12 updates."""
+    res = _run_ranks(2, [flag])
     assert all(r["ok"] and r["graph"] == "one" for r in res)
     assert res[0]["sums"] == res[1]["sums"]
