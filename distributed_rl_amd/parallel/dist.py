@@ -108,8 +108,9 @@ class Dist:
             if mode == "1":
                 raise RuntimeError("DRL_XGMI_AR=1 but the direct xGMI all-reduce is not usable: %s" % (why or "mismatch"))
             if self.rank == 0:
+                import sys
                 print("[dist] direct xGMI all-reduce not used (%s); gradients go through RCCL" % (why or "verification failed"),
-                      flush=True)
+                      file=sys.stderr, flush=True)
             return None
         self.xgmi = ar
         self._xgmi_stream = torch.cuda.Stream(self.device)
