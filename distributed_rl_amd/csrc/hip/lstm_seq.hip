@@ -151,6 +151,126 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet 
     }
 }
 
+// ---- coalesced exchange form --------------------------------------------------------------------------------------
+// In the form above a wave's h load instruction touches 16 rows x 64 bytes: half of 16 different 128-byte lines, and the
+// other halves are fetched again by the next instruction - sc1 loads are not kept by any cache on the way. Here h_t
+// travels through an exchange buffer laid out in CONSUMER order, [parity][wave][ks][lane][8 x bf16]: one load instruction
+// of a wave is one contiguous kilobyte (8 whole lines, each fetched once). Producers scatter their 8-byte pieces into it
+// (write-through stores as before); hs keeps its plain layout for the kernels outside (ordinary stores, nobody inside the
+// launch reads them). Same counter protocol. Two parity slots: slot (t+1)&1 last held h_{t-1}, which every workgroup had
+// finished reading before it arrived at the barrier this workgroup passed to start step t.
+struct LstmXNet {
+    const float* xg; const bf16_t* w_hh; bf16_t* hs; float* cs; bf16_t* gates;
+    bf16_t* hx;           // [2][4][H/32][64][8] bf16 = 2 x 64 KB, then the arrival counter at byte 192 K
+};
+#define HX_SYNC_BYTE_OFFSET (192 * 1024)
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1, int T, int M, int* err) {
+    constexpr int NWG = 4 * HD / 64, NKS = HD / 32;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int net = blockIdx.x / NWG, wg = blockIdx.x % NWG;
+    const LstmXNet a = net ? n1 : n0;
+    int* sync = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(a.hx) + HX_SYNC_BYTE_OFFSET);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g4 = lane >> 4;
+    for (int i = tid; i < 4 * NKS * 64; i += 256) {
+        const int l = i & 63, f = i >> 6, ks = f % NKS, nt = f / NKS, ii = l & 15;
+        const int n = 64 * wg + 4 * (4 * (ii >> 2) + nt) + (ii & 3);
+        *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = *reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + ks * 32 + (l >> 4) * 8);
+    }
+    __syncthreads();
+    const bool active = wave * 16 < M;
+    const int m = min(wave * 16 + r, M - 1);
+    const int u0 = 16 * wg + 4 * g4;                 // this lane owns units u0 .. u0+3 of row m
+    float c[4];
+    {
+        const float4 c0 = *reinterpret_cast<const float4*>(a.cs + (size_t)m * HD + u0);
+        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+    }
+    const auto hx_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hx, 0, 2 * 4 * NKS * 64 * 16, 0x00020000);
+    // where this lane's 4 units live in the consumer-ordered buffer: fragment u0/32, piece (u0%32)/8 of row r, half (u0%8)/4
+    const unsigned st_off = (unsigned)((((wave * NKS + u0 / 32) * 64 + ((u0 & 31) >> 3) * 16 + r) * 8 + (u0 & 4)) * sizeof(bf16_t));
+    const unsigned ld_off = (unsigned)(((wave * NKS) * 64 + lane) * 16);
+    constexpr unsigned SLOT = 4 * NKS * 64 * 16;     // bytes per parity slot
+    __shared__ int s_dead;
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float4 xq[4];
+        const float* xrow = a.xg + ((size_t)t * M + m) * (4 * HD) + 4 * u0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const float4*>(xrow + 4 * q);
+        bf16x8 hf[NKS];
+        if (t == 0) {                                          // initial state: written before the launch, plain loads
+            const uint4* hrow = reinterpret_cast<const uint4*>(a.hs + (size_t)m * HD + g4 * 8);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) hf[ks] = __builtin_bit_cast(bf16x8, hrow[ks * 4]);
+        } else {
+            grid_wait(sync, NWG * t, err, &s_dead);
+            const unsigned base = (t & 1) * SLOT + ld_off;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {                 // one contiguous KB per instruction, sc1 (never an L1 hit)
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, base + ks * 1024, 0, 16);
+                hf[ks] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(nt * NKS + ks) * 64 + lane) * 16);
+                acc[nt] = mfma16_(wf, hf[ks], acc[nt]);
+            }
+        float h[4];
+        uint32_t gp[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float ig = sigm_(acc[nt][0] + xq[nt].x), fg = sigm_(acc[nt][1] + xq[nt].y);
+            const float gg = tanh_(acc[nt][2] + xq[nt].z), og = sigm_(acc[nt][3] + xq[nt].w);
+            c[nt] = fg * c[nt] + ig * gg;
+            h[nt] = og * tanh_(c[nt]);
+            gp[2 * nt] = pack_bf2(ig, fg);
+            gp[2 * nt + 1] = pack_bf2(gg, og);
+        }
+        if (active) {
+            const uint32_t h01 = pack_bf2(h[0], h[1]), h23 = pack_bf2(h[2], h[3]);
+            if (t + 1 < T)                                     // the hand-off first: it is what the other workgroups wait for
+                __hip_atomic_store(reinterpret_cast<u64_t*>(reinterpret_cast<uint8_t*>(a.hx) + ((t + 1) & 1) * SLOT + st_off),
+                                   (u64_t)h01 | ((u64_t)h23 << 32), RLX_AGENT);
+            const size_t o = ((size_t)(t + 1) * M + m) * HD + u0;
+            *reinterpret_cast<uint2*>(a.hs + o) = make_uint2(h01, h23);
+            *reinterpret_cast<float4*>(a.cs + o) = make_float4(c[0], c[1], c[2], c[3]);
+            if (a.gates) {
+                uint4* gout = reinterpret_cast<uint4*>(a.gates + ((size_t)t * M + m) * (4 * HD) + 4 * u0);
+                gout[0] = make_uint4(gp[0], gp[1], gp[2], gp[3]);
+                gout[1] = make_uint4(gp[4], gp[5], gp[6], gp[7]);
+            }
+        }
+        if (t + 1 < T) grid_arrive(sync);
+    }
+}
+
+// hx0 / hx1: exchange buffers of 256 KB each (lstm_hx); the arrival counter inside is zeroed here.
+DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, void* hx0,
+                                const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, void* hx1, int n_nets,
+                                int T, int M, int H, int* err, hipStream_t s) {
+    if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2 || !hx0 || (n_nets == 2 && !hx1)) return -1;
+    if (hipMemsetAsync((uint8_t*)hx0 + HX_SYNC_BYTE_OFFSET, 0, 4, s) != hipSuccess) return -2;
+    if (n_nets == 2 && hipMemsetAsync((uint8_t*)hx1 + HX_SYNC_BYTE_OFFSET, 0, 4, s) != hipSuccess) return -2;
+    LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, (bf16_t*)hx0};
+    LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, (bf16_t*)hx1};
+    constexpr int LDS = 4 * (512 / 32) * 1024;
+    auto k0 = k_lstm_seq_fwd_x<512>;
+    static bool once = (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+    (void)once;
+    k0<<<n_nets * (4 * 512 / 64), 256, LDS, s>>>(a, b, T, M, err);
+    return (int)hipGetLastError();
+}
+
 // Runs T steps for one (n_nets = 1) or two networks. sync: 2 ints, err: 1 int (device memory; zeroed here).
 DRL_API int drl_lstm_seq_fwd(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, const float* xg1,
                              const void* w1, void* hs1, float* cs1, void* gates1, int n_nets, int T, int M, int H, int* sync,

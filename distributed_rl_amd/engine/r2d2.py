@@ -48,6 +48,7 @@ class SeqNetBuffers:
         self.q = torch.zeros(N, n_action, device=device)
         self.sync = torch.zeros(4, dtype=torch.int32, device=device)   # persistent-recurrence arrival counters
         self.err = torch.zeros(4, dtype=torch.int32, device=device)    # ... and its timeout flag
+        self.hx = H.lstm_hx(device)                                     # exchange buffer of the persistent recurrence
 
 
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
@@ -80,7 +81,10 @@ def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, p
     w_hh = wb.view("lstm.w_hh")
     if persistent:
         gates = buf.gates[t0:t1] if buf.gates is not None else None
-        H.lstm_seq_fwd([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates)], t1 - t0, B, Hd, buf.sync, buf.err)
+        if H.LSTM_XCHG:
+            H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx)], t1 - t0, B, Hd, buf.err)
+        else:
+            H.lstm_seq_fwd([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates)], t1 - t0, B, Hd, buf.sync, buf.err)
     else:
         for t in range(t0, t1):
             H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
@@ -164,7 +168,8 @@ class R2D2Engine:
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
-        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "0") != "0"    # measured equal (3.26-3.30 ms either way)
+        # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
+        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1" if H.LSTM_XCHG else "0") != "0"
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
         fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
@@ -224,10 +229,13 @@ class R2D2Engine:
                     # nets against 655 us for one, so the second network rides along almost for free
                     t0, t1 = st_
                     with fj.fork(0):
-                        H.lstm_seq_fwd([(self.on.xg[t0:t1], self.Pb.view("lstm.w_hh"), self.on.hs[t0:t1 + 1], self.on.cs[t0:t1 + 1],
-                                         self.on.gates[t0:t1]),
-                                        (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1],
-                                         None)], t1 - t0, B, Hd, self.on.sync, self.on.err)
+                        on_net = (self.on.xg[t0:t1], self.Pb.view("lstm.w_hh"), self.on.hs[t0:t1 + 1], self.on.cs[t0:t1 + 1],
+                                  self.on.gates[t0:t1])
+                        tg_net = (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1], None)
+                        if H.LSTM_XCHG:
+                            H.lstm_seq_fwd_x([on_net + (self.on.hx,), tg_net + (self.tg.hx,)], t1 - t0, B, Hd, self.on.err)
+                        else:
+                            H.lstm_seq_fwd([on_net, tg_net], t1 - t0, B, Hd, self.on.sync, self.on.err)
                 else:
                     with fj.fork(2):
                         seq_recurrence(T, B, Hd, self.Tb, self.tg, self.persistent_lstm, steps=st_)

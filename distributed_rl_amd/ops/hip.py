@@ -533,6 +533,33 @@ def lstm_seq_fwd(nets, T: int, M: int, Hd: int, sync: torch.Tensor, err: torch.T
     _ck(native.hip().drl_lstm_seq_fwd(*args, len(nets), T, M, Hd, _p(sync), _p(err), _s()), "lstm_seq_fwd")
 
 
+# exchange-buffer form of the persistent recurrence (h travels in consumer order: 4.6 vs 5.5 us per step); 0 = plain form
+LSTM_XCHG = os.environ.get("DRL_LSTM_XCHG", "1") != "0"
+
+
+def lstm_hx(device) -> torch.Tensor:
+    """Scratch of one network for :func:`lstm_seq_fwd_x`: 256 KB (two 64 KB parity slots + the arrival counter)."""
+    return torch.zeros(32768, dtype=torch.int64, device=device)
+
+
+def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
+    """As :func:`lstm_seq_fwd`, but h is handed between the workgroups through an exchange buffer laid out in consumer
+    order (csrc/hip/lstm_seq.hip, coalesced exchange form). ``nets`` = list of (xg, w_hh, hs, cs, gates | None, hx) with
+    hx from :func:`lstm_hx` (one per network, not shared between launches that may run at the same time)."""
+    assert 1 <= len(nets) <= 2
+    _chk(err, torch.int32, "err")
+    args = []
+    for xg, w_hh, hs, cs, gates, hx in nets:
+        _chk(xg, torch.float32, "xg"); _chk(w_hh, torch.bfloat16, "w_hh"); _chk(hs, torch.bfloat16, "hs"); _chk(cs, torch.float32, "cs")
+        _chk(hx, torch.int64, "hx")
+        assert xg.numel() == T * M * 4 * Hd and hs.numel() == (T + 1) * M * Hd and cs.numel() == (T + 1) * M * Hd
+        assert w_hh.shape == (4 * Hd, Hd) and (gates is None or gates.numel() == T * M * 4 * Hd) and hx.numel() == 32768
+        args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates), _p(hx)]
+    if len(nets) == 1:
+        args += [None] * 6
+    _ck(native.hip().drl_lstm_seq_fwd_x(*args, len(nets), T, M, Hd, _p(err), _s()), "lstm_seq_fwd_x")
+
+
 def lstm_seq_supported(M: int, Hd: int) -> bool:
     return Hd == 512 and 0 < M <= 64 and M % 16 == 0
 

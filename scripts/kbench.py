@@ -184,6 +184,10 @@ def main():
             H.lstm_step(hss[t], whh, xgs[t], css[t], hss[t + 1], css[t + 1], gts[t])
     cases["lstm_120_steps"] = (steps120, 2 * 64 * 2048 * 512 * Ts, 0)
     cases["lstm_seq_1net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts)], Ts, 64, 512, sync, err), 2 * 64 * 2048 * 512 * Ts, 0)
+    hx1, hx2 = H.lstm_hx(DEV), H.lstm_hx(DEV)
+    cases["lstm_seq_x"] = (lambda: H.lstm_seq_fwd_x([(xgs, whh, hss, css, gts, hx1)], Ts, 64, 512, err), 2 * 64 * 2048 * 512 * Ts, 0)
+    cases["lstm_seq_x_2net"] = (lambda: H.lstm_seq_fwd_x([(xgs, whh, hss, css, gts, hx1), (xgs, whh, hss2, css2, None, hx2)], Ts, 64,
+                                                            512, err), 2 * 2 * 64 * 2048 * 512 * Ts, 0)
     cases["lstm_seq_2net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts), (xgs, whh, hss2, css2, None)], Ts, 64, 512, sync, err),
                               2 * 2 * 64 * 2048 * 512 * Ts, 0)
     # BPTT: 80 steps as the engine issues them - two launches per step vs the fused one-launch step

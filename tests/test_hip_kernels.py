@@ -705,7 +705,7 @@ def test_lstm_step_and_persistent_sequence(hip, M):
     T, Hd = 12, 512
     w_k, xg_k, h0, c0, hs_ref, cs_ref = _lstm_case(T, M, Hd, 100 + M)
     outs = []
-    for mode in ("step", "seq", "seq2"):
+    for mode in ("step", "seq", "seq2", "xchg", "xchgx2"):
         hs = torch.zeros(T + 1, M, Hd, dtype=torch.bfloat16, device=DEV)
         cs = torch.zeros(T + 1, M, Hd, device=DEV)
         gates = torch.zeros(T, M, 4 * Hd, dtype=torch.bfloat16, device=DEV)
@@ -713,6 +713,17 @@ def test_lstm_step_and_persistent_sequence(hip, M):
         if mode == "step":
             for t in range(T):
                 H.lstm_step(hs[t], w_k, xg_k[t], cs[t], hs[t + 1], cs[t + 1], gates[t])
+        elif mode.startswith("xchg"):                               # exchange-buffer form of the persistent recurrence
+            err = torch.zeros(1, dtype=torch.int32, device=DEV)
+            nets = [(xg_k, w_k, hs, cs, gates, H.lstm_hx(DEV))]
+            if mode == "xchgx2":
+                hs2, cs2 = hs.clone(), cs.clone()
+                nets.append((xg_k, w_k, hs2, cs2, None, H.lstm_hx(DEV)))
+            for _ in range(2):                                      # twice: the scratch is reused across launches
+                H.lstm_seq_fwd_x(nets, T, M, Hd, err)
+            assert int(err.item()) == 0
+            if mode == "xchgx2":
+                assert torch.equal(hs2, hs) and torch.equal(cs2, cs)
         else:
             sync, err = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
             nets = [(xg_k, w_k, hs, cs, gates)]
