@@ -161,9 +161,35 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet 
 // finished reading before it arrived at the barrier this workgroup passed to start step t.
 struct LstmXNet {
     const float* xg; const bf16_t* w_hh; bf16_t* hs; float* cs; bf16_t* gates;
-    bf16_t* hx;           // [2][4][H/32][64][8] bf16 = 2 x 64 KB, then the arrival counter at byte 192 K
+    bf16_t* hx;           // [2][4][H/32][64][8] bf16 = 2 x 64 KB, then the arrival flags at byte 192 K
 };
 #define HX_SYNC_BYTE_OFFSET (192 * 1024)
+
+// Arrival flags instead of a counter: atomics on one address serialise (~35 ns each, so 32 simultaneous arrivals take
+// > 1 us to land). Every workgroup owns one flag word (FLAG_STRIDE ints apart) and STORES the number of the step it has
+// finished (a write-through store, no read-modify-write); lanes 0..NWG-1 of the polling wave watch one flag each.
+#ifndef DRL_LSTM_FLAG_STRIDE
+#define DRL_LSTM_FLAG_STRIDE 32
+#endif
+__device__ __forceinline__ void grid_wait_fl(int* flags, int nwg, int target, int* err, int* s_dead) {
+    if (threadIdx.x < 64 && !*s_dead) {
+        const bool mine = (int)threadIdx.x < nwg;
+        int it = 0;
+        while (true) {
+            const int v = mine ? __hip_atomic_load(flags + threadIdx.x * DRL_LSTM_FLAG_STRIDE, RLX_AGENT) : target;
+            if (__all(v >= target)) break;
+            if (++it > SPIN_LIMIT) { if (threadIdx.x == 0) { atomicExch(err, 1); *s_dead = 1; } break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void grid_arrive_fl(int* flags, int wg, int step_done) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave's h stores are acknowledged ...
+    __syncthreads();                                          // ... before the one lane that raises the flag
+    if (threadIdx.x == 0) __hip_atomic_store(flags + wg * DRL_LSTM_FLAG_STRIDE, step_done, RLX_AGENT);
+}
 
 template <int HD>
 __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1, int T, int M, int* err) {
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) hf[ks] = __builtin_bit_cast(bf16x8, hrow[ks * 4]);
         } else {
-            grid_wait(sync, NWG * t, err, &s_dead);
+            grid_wait_fl(sync, NWG, t, err, &s_dead);
             const unsigned base = (t & 1) * SLOT + ld_off;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {                 // one contiguous KB per instruction, sc1 (never an L1 hit)
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
                 gout[1] = make_uint4(gp[4], gp[5], gp[6], gp[7]);
             }
         }
-        if (t + 1 < T) grid_arrive(sync);
+        if (t + 1 < T) grid_arrive_fl(sync, wg, t + 1);
     }
 }
 
@@ -259,8 +285,8 @@ DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, floa
                                 const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, void* hx1, int n_nets,
                                 int T, int M, int H, int* err, hipStream_t s) {
     if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2 || !hx0 || (n_nets == 2 && !hx1)) return -1;
-    if (hipMemsetAsync((uint8_t*)hx0 + HX_SYNC_BYTE_OFFSET, 0, 4, s) != hipSuccess) return -2;
-    if (n_nets == 2 && hipMemsetAsync((uint8_t*)hx1 + HX_SYNC_BYTE_OFFSET, 0, 4, s) != hipSuccess) return -2;
+    if (hipMemsetAsync((uint8_t*)hx0 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
+    if (n_nets == 2 && hipMemsetAsync((uint8_t*)hx1 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
     LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, (bf16_t*)hx0};
     LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, (bf16_t*)hx1};
     constexpr int LDS = 4 * (512 / 32) * 1024;
