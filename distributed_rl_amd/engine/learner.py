@@ -127,6 +127,10 @@ class HipLearner:
         cfg = self.cfg
         if not self.wait_memory(max(cfg.batch_size, cfg.start_memory_size), warmup_timeout):
             raise TimeoutError("replay never reached the learn-start size")
+        if self.dist is not None:
+            # shards fill at different rates; the steps that follow contain collectives with bounded waits (the direct
+            # xGMI all-reduce polls its peers for at most DRL_XGMI_TIMEOUT_S), so the ranks start them together
+            self.dist.barrier()
         end = None if max_steps is None else self.step + max_steps
         t_last, n_last = time.time(), self.step
         while end is None or self.step < end:

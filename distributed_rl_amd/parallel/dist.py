@@ -137,7 +137,7 @@ class Dist:
             torch.cuda.synchronize(self.device)
             if ar.error() != 0 or not torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4):
                 return False
-        ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "20")))
+        ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
         return True
 
     def check_health(self) -> None:

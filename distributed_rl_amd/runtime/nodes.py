@@ -172,7 +172,10 @@ def learner_main(argv=None) -> int:
     n_action = envs.n_action_of(args.env)             # the reference builds a whole env just for this (learner_node.py:20)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and device.type == "cuda":
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        lr_ = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("DRL_SHARE_GPU") == "1":         # rehearsal: more ranks than GPUs (see parallel/dist.py)
+            lr_ %= torch.cuda.device_count()
+        device = torch.device("cuda", lr_)
     metrics = make_metrics("learner" if rank == 0 else "learner_r%d" % rank, args.visdomserver, args.log_dir,
                            args.quiet or rank > 0)
     exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=True, host=args.redisserver,

@@ -189,3 +189,16 @@ def test_r2d2_runtime_actor_with_engine_publishes_sequences(run_id):
     b = blocks[0]
     assert b["frames"].shape[1:] == (cfg.total_len, 84, 84, 4) and b["h0"].shape[1] == 512
     assert np.isfinite(b["prio"]).all() and (b["prio"] >= 0).all()
+
+
+def test_run_sh_two_data_parallel_hip_learners():
+    """``learner_gpus=2`` with the gfx950 engines: ./run.sh starts two learner ranks (here sharing the one GPU, handles
+    exchanged over gloo) + two actors; the gradient all-reduce is the direct xGMI kernel inside each rank's step graph
+    (DRL_XGMI_AR=1: required, no fallback); rank 0 writes the checkpoints."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DRL_DIST_BACKEND="gloo", DRL_SHARE_GPU="1", DRL_XGMI_AR="1",
+               DRL_E2E_CONF="config/all_dp2.conf", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "e2e_gpu.sh"), "ape_x"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=170)
+    assert r.returncode == 0 and "E2E ape_x OK" in r.stdout, r.stdout[-3000:]
