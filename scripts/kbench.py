@@ -92,6 +92,20 @@ def main():
         cases["conv3_fwd_glds%d" % v] = (lambda v=v: H.conv_fwd(3, a2, w3, b3, a3, F, direct=False, variant=v), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
     for v in (0, 2, 3, 5, 6, 10, 11, 13, 14):
         cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
+    # two networks per launch (Ape-X learner: online net on F frames + target net on F/2 frames)
+    xoff = (torch.arange(F, device=DEV) * 28224).long()
+    t1, t2 = torch.zeros_like(a1[:B]), torch.zeros_like(a2[:B])
+    t3, th = torch.zeros_like(a3[:B]), torch.zeros_like(h[:B])
+    q1, q2 = torch.zeros(F, 4, device=DEV), torch.zeros(B, 4, device=DEV)
+    wa, wv, ba, bv = bf(4, 512, scale=0.05), bf(1, 512, scale=0.05), torch.randn(4, device=DEV), torch.randn(1, device=DEV)
+    FB = F + B
+    cases["conv1_fwd_dual"] = (lambda: H.conv_fwd_dual(1, x, F, w1, b1, a1, None, B, w1, b1, t1, frame_off1=xoff, frame_off2=xoff[B:]),
+                               2 * FB * 400 * 32 * 256, FB * (28224 + 25600))
+    cases["conv2_fwd_dual"] = (lambda: H.conv_fwd_dual(2, a1, F, w2, b2, a2, a1[:B], B, w2, b2, t2), 2 * FB * 81 * 64 * 512, FB * (25600 + 10368))
+    cases["conv3_fwd_dual"] = (lambda: H.conv_fwd_dual(3, a2, F, w3, b3, a3, a2[:B], B, w3, b3, t3), 2 * FB * 49 * 64 * 576, FB * (10368 + 6272))
+    cases["fc1_fwd_dual"] = (lambda: H.gemm_nt_dual(a3, wfc, bfc, h, a3[:B], wfc, bfc, th, 1024, 3136, flags=H.EPI_RELU),
+                             2 * FB * 1024 * 3136, 2 * (FB * 3136 + 2 * 1024 * 3136 + FB * 1024))
+    cases["head_fwd_dual"] = (lambda: H.head_fwd_dual(h, wa, ba, wv, bv, q1, th, wa, ba, wv, bv, q2), 2 * FB * 5 * 512, FB * 2048)
     hf = torch.zeros(F, 1024, device=DEV)
     for sp in (2, 4, 8):
         cases["fc1_fwd_v1_sk%d" % sp] = (lambda sp=sp: H.gemm(H.NT, a3, wfc, hf, F, 1024, 3136, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=sp, big=1), 2 * F * 1024 * 3136, 0)

@@ -22,7 +22,7 @@ for f in glob.glob("gpurun_out/pmc/**/k_counter_collection.csv", recursive=True)
         acc[r["Kernel_Name"][:70]][r["Counter_Name"]] += float(r["Counter_Value"])
     break
 for k, v in acc.items():
-    if ("k_multi" in k or "k_gemm_glds" in k or "k_lstm" in k or "k_apex_td_dh" in k) and "void at::" not in k:
+    if any(t in k for t in ("k_multi", "k_gemm_glds", "k_lstm", "k_apex_td_dh", "k_conv1_direct", "k_head_fwd_dual")) and "void at::" not in k:
         print(k, dict(v))
 PY
   done
