@@ -36,6 +36,42 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
     return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
 }
 
+// conv1 in f16 instead of bf16 (DRL_CONV1_F16): the kernel is vector-issue bound (59 % of its wave cycles wait for an
+// instruction slot) and most of its vector work is the u8 -> bf16 conversion: 12 instructions per 8 pixels. In f16 the
+// conversion is ONE v_perm_b32 per 2 pixels: the half 0x6400 | b is exactly 1024 + b (ulp 1 at 2^10), so a byte next to a
+// constant 0x64 byte already is a usable operand. The accumulators start at -1024 * sum_k w[n][k], which cancels the
+// offset exactly up to fp32 rounding at |1024 * sum w| ~ 1e3 (1e-4 pixel units, 5e-7 after the /255). The weights are
+// converted bf16 -> f16 once per wave (exact: |w| < 65504, f16 has more mantissa bits; |w| < 6e-5 goes denormal).
+#ifndef DRL_CONV1_F16
+#define DRL_CONV1_F16 1
+#endif
+#ifndef DRL_CONV1_WAVES_PER_CU
+#define DRL_CONV1_WAVES_PER_CU 8     // wave slots the tiles are dealt to (per CU): fewer waves = fewer weight set-ups
+#endif
+typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16h(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), c, 0, 0, 0);
+}
+// 8 u8 -> 8 f16 holding 1024 + pixel: 4 x v_perm_b32
+__device__ __forceinline__ uint4 u8x8_to_f16_biased(uint2 v) {
+    const uint32_t k = 0x64646464u;
+    return make_uint4(__builtin_amdgcn_perm(k, v.x, 0x04010400u), __builtin_amdgcn_perm(k, v.x, 0x04030402u),
+                      __builtin_amdgcn_perm(k, v.y, 0x04010400u), __builtin_amdgcn_perm(k, v.y, 0x04030402u));
+}
+// 8 bf16 -> 8 f16, and the sum of the 8 values as the MFMA will see them
+__device__ __forceinline__ uint4 bf16x8_to_f16(bf16x8 v, float& sum) {
+    typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = bf2f((bf16_t)v[2 * i]), b = bf2f((bf16_t)v[2 * i + 1]);
+        const h2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
+        sum += (float)h[0] + (float)h[1];
+        o[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // conv1: u8 [*,84,84,4] (dense batch, or frames of a replay store addressed by byte offsets) -> bf16 [n,20,20,32]
 // ---------------------------------------------------------------------------------------------------------------
@@ -64,12 +100,33 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
     // every wave owns `per` CONSECUTIVE 16-row tiles (neighbouring output pixels overlap in the input: L1/L2 hits)
     const int t0 = (blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
     if (t0 >= ntiles) return;                       // wave-uniform: no barriers in this kernel
+#if DRL_CONV1_F16
+    uint4 wf[2][8];
+    float acc0[2][4];                               // accumulator start: -1024 * (sum over k of this lane's channels' weights)
+    {
+        float csum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                wf[t][s] = bf16x8_to_f16(*reinterpret_cast<const bf16x8*>(w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8),
+                                         csum[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {               // lanes r, r+16, r+32, r+48 hold the four k-quarters of MFMA row r
+            csum[t] += __shfl_xor(csum[t], 16, WAVE);
+            csum[t] += __shfl_xor(csum[t], 32, WAVE);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc0[t][i] = -1024.0f * __shfl(csum[t], g * 4 + i, WAVE);   // accumulator row g*4+i
+        }
+    }
+#else
     bf16x8 wf[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             wf[t][s] = *reinterpret_cast<const bf16x8*>(w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8);
+#endif
     // MFMA row i of weight tile t is output channel (i/4)*8 + t*4 + i%4 (a free permutation of the weight rows): the
     // lane that ends up with accumulator rows g*4..g*4+3 of both tiles then owns the 8 CONSECUTIVE channels g*8..g*8+7
     // of its pixel: one 16-byte store per lane, 1 KB contiguous per wave and tile.
@@ -108,6 +165,15 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
 #pragma unroll
         for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + s * 336);    // tile + 1
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
+#if DRL_CONV1_F16
+        f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint4 xf = u8x8_to_f16_biased(cur[s]);
+            acc[0] = mfma16h(wf[0][s], xf, acc[0]);
+            acc[1] = mfma16h(wf[1][s], xf, acc[1]);
+        }
+#else
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -115,6 +181,7 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
             acc[0] = mfma16(wf[0][s], xf, acc[0]);
             acc[1] = mfma16(wf[1][s], xf, acc[1]);
         }
+#endif
         const int m = tile * 16 + r;
         if (m < M) {
             constexpr float SC = 1.0f / 255.0f;          // pixel normalisation x/255 folded into the epilogue
@@ -256,7 +323,7 @@ DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const f
     if (layer == 1) {
         const int M = frames * 400;
         int grid;
-        const int per = plan((M + 15) / 16, 256 * 16, 4, &grid);
+        const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
         const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
         if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
         else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
@@ -288,7 +355,7 @@ DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int f
                                void* out2, hipStream_t s) {
     if (frames1 <= 0 || frames2 <= 0 || !frame_off1 || !frame_off2) return -1;
     int g1, g2;
-    const int slots = 256 * 16;
+    const int slots = 256 * DRL_CONV1_WAVES_PER_CU;
     const int M1 = frames1 * 400, M2 = frames2 * 400;
     // split the resident wave slots in proportion to the work so both networks finish together
     const int s1 = (int)((long long)slots * M1 / (M1 + M2)), s2 = slots - s1;
