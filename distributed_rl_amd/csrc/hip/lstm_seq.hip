@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet 
 // finished reading before it arrived at the barrier this workgroup passed to start step t.
 struct LstmXNet {
     const float* xg; const bf16_t* w_hh; bf16_t* hs; float* cs; bf16_t* gates;
+    const float* bias;    // [4H] added to xg on the fly (nullptr: xg already holds it) - saves a pass over xg after a library GEMM
     bf16_t* hx;           // [2][4][H/32][64][8] bf16 = 2 x 64 KB, then the arrival flags at byte 192 K
 };
 #define HX_SYNC_BYTE_OFFSET (192 * 1024)
@@ -214,6 +215,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
         const float4 c0 = *reinterpret_cast<const float4*>(a.cs + (size_t)m * HD + u0);
         c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
     }
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bq[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + 4 * u0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const auto hx_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hx, 0, 2 * 4 * NKS * 64 * 16, 0x00020000);
     // where this lane's 4 units live in the consumer-ordered buffer: fragment u0/32, piece (u0%32)/8 of row r, half (u0%8)/4
     const unsigned st_off = (unsigned)((((wave * NKS + u0 / 32) * 64 + ((u0 & 31) >> 3) * 16 + r) * 8 + (u0 & 4)) * sizeof(bf16_t));
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
         uint32_t gp[8];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const float ig = sigm_(acc[nt][0] + xq[nt].x), fg = sigm_(acc[nt][1] + xq[nt].y);
-            const float gg = tanh_(acc[nt][2] + xq[nt].z), og = sigm_(acc[nt][3] + xq[nt].w);
+            const float ig = sigm_(acc[nt][0] + xq[nt].x + bq[nt].x), fg = sigm_(acc[nt][1] + xq[nt].y + bq[nt].y);
+            const float gg = tanh_(acc[nt][2] + xq[nt].z + bq[nt].z), og = sigm_(acc[nt][3] + xq[nt].w + bq[nt].w);
             c[nt] = fg * c[nt] + ig * gg;
             h[nt] = og * tanh_(c[nt]);
             gp[2 * nt] = pack_bf2(ig, fg);
@@ -281,14 +286,14 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
 }
 
 // hx0 / hx1: exchange buffers of 256 KB each (lstm_hx); the arrival counter inside is zeroed here.
-DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, void* hx0,
-                                const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, void* hx1, int n_nets,
+DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, const float* bias0, void* hx0,
+                                const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, const float* bias1, void* hx1, int n_nets,
                                 int T, int M, int H, int* err, hipStream_t s) {
     if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2 || !hx0 || (n_nets == 2 && !hx1)) return -1;
     if (hipMemsetAsync((uint8_t*)hx0 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
     if (n_nets == 2 && hipMemsetAsync((uint8_t*)hx1 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
-    LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, (bf16_t*)hx0};
-    LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, (bf16_t*)hx1};
+    LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, bias0, (bf16_t*)hx0};
+    LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, bias1, (bf16_t*)hx1};
     constexpr int LDS = 4 * (512 / 32) * 1024;
     auto k0 = k_lstm_seq_fwd_x<512>;
     static bool once = (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);

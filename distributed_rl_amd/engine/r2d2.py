@@ -51,10 +51,18 @@ class SeqNetBuffers:
         self.hx = H.lstm_hx(device)                                     # exchange buffer of the persistent recurrence
 
 
+def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
+    """The library GEMM has no bias epilogue; instead of a second pass over xg (n x 4H fp32) the exchange-form recurrence
+    adds b_ih + b_hh on the fly. True when both ends agree on that (same n in seq_torso_forward and seq_recurrence)."""
+    return persistent and H.LSTM_XCHG and H.use_lib_gemm(n, 4 * Hd, 3136)
+
+
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
-                      wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None) -> None:
+                      wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None,
+                      persistent: bool = False) -> None:
     """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
-    all T) + ONE input-projection GEMM for those steps (throughput-bound)."""
+    all T) + ONE input-projection GEMM for those steps (throughput-bound). ``persistent``: the recurrence that follows is
+    the persistent kernel (it may take over the bias add, see defer_xg_bias)."""
     t0, t1 = steps if steps is not None else (0, T)
     r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
     x = frames if frame_off is not None else frames[r0:r1]
@@ -68,13 +76,14 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
     if H.use_lib_gemm(n, 4 * Hd, 3136):        # big plain product: hipBLASLt (see ops.hip.lib_gemm), bias as a second pass
         H.lib_gemm(H.NT, a3, wb.view("lstm.w_ih"), xg)
-        xg.add_(bsum)
+        if not defer_xg_bias(n, Hd, persistent):
+            xg.add_(bsum)
     else:
         H.gemm(H.NT, a3, wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
 
 
 def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, persistent: bool,
-                   steps: Optional[Tuple[int, int]] = None) -> None:
+                   steps: Optional[Tuple[int, int]] = None, bsum: Optional[torch.Tensor] = None) -> None:
     """The recurrence over time steps ``steps`` (default: all T) from the state in buf.hs[t0] / buf.cs[t0]: one persistent
     launch, or one launch of the EPI_LSTM GEMM per step; latency-bound."""
     t0, t1 = steps if steps is not None else (0, T)
@@ -82,7 +91,10 @@ def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, p
     if persistent:
         gates = buf.gates[t0:t1] if buf.gates is not None else None
         if H.LSTM_XCHG:
-            H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx)], t1 - t0, B, Hd, buf.err)
+            bias = bsum if defer_xg_bias((t1 - t0) * B, Hd, persistent) else None
+            assert bias is not None or not defer_xg_bias((t1 - t0) * B, Hd, persistent), "seq_recurrence needs bsum"
+            H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx, bias)], t1 - t0, B, Hd,
+                             buf.err)
         else:
             H.lstm_seq_fwd([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates)], t1 - t0, B, Hd, buf.sync, buf.err)
     else:
@@ -100,9 +112,9 @@ def seq_heads(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNet
 
 
 def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers,
-                          persistent: bool) -> None:
-    """Recurrence over all T steps + heads."""
-    seq_recurrence(T, B, Hd, wb, buf, persistent)
+                          persistent: bool, bsum: Optional[torch.Tensor] = None) -> None:
+    """Recurrence over all T steps + heads (``bsum``: see defer_xg_bias; pass what seq_torso_forward was given)."""
+    seq_recurrence(T, B, Hd, wb, buf, persistent, bsum=bsum)
     seq_heads(T, B, Hd, wb, wf, buf)
 
 
@@ -111,8 +123,8 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
     """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0].
     Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
     sequence-priority pass (dense frames, ``frame_off`` None)."""
-    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum)
-    seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent)
+    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum, persistent=persistent)
+    seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent, bsum=bsum)
 
 
 class R2D2Engine:
@@ -219,11 +231,12 @@ class R2D2Engine:
             H.gather_state(r.c0, r.idx, self.tg.cs[0], None)
             dual = self.persistent_lstm and self.dual_lstm
             for st_ in self.fwd_bounds:
-                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_)
+                pl = self.persistent_lstm
+                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_, persistent=pl)
                 if not dual:
                     with fj.fork(0):
-                        seq_recurrence(T, B, Hd, self.Pb, self.on, self.persistent_lstm, steps=st_)
-                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_)
+                        seq_recurrence(T, B, Hd, self.Pb, self.on, pl, steps=st_, bsum=self.bsum_on)
+                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_, persistent=pl)
                 if dual:
                     # both recurrences of the chunk in ONE persistent launch (64 workgroups): 685 us for 120 steps of two
                     # nets against 655 us for one, so the second network rides along almost for free
@@ -233,21 +246,24 @@ class R2D2Engine:
                                   self.on.gates[t0:t1])
                         tg_net = (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1], None)
                         if H.LSTM_XCHG:
-                            H.lstm_seq_fwd_x([on_net + (self.on.hx,), tg_net + (self.tg.hx,)], t1 - t0, B, Hd, self.on.err)
+                            dfr = defer_xg_bias((t1 - t0) * B, Hd, True)
+                            H.lstm_seq_fwd_x([on_net + (self.on.hx, self.bsum_on if dfr else None),
+                                              tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err)
                         else:
                             H.lstm_seq_fwd([on_net, tg_net], t1 - t0, B, Hd, self.on.sync, self.on.err)
                 else:
                     with fj.fork(2):
-                        seq_recurrence(T, B, Hd, self.Tb, self.tg, self.persistent_lstm, steps=st_)
+                        seq_recurrence(T, B, Hd, self.Tb, self.tg, pl, steps=st_, bsum=self.bsum_tg)
             with fj.fork(0):
                 seq_heads(T, B, Hd, self.Pb, self.P, self.on)
             with fj.fork(2 if not dual else 0):
                 seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
         else:
-            seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on)
+            seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on,
+                              persistent=self.persistent_lstm)
             with fj.fork(0):                                        # target net: queued behind the online torso
                 self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
-            seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm)
+            seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm, bsum=self.bsum_on)
         H.is_weights(r.prio, self.st, self.w)
         fj.join()
         H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,

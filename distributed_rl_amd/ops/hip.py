@@ -544,19 +544,25 @@ def lstm_hx(device) -> torch.Tensor:
 
 def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
     """As :func:`lstm_seq_fwd`, but h is handed between the workgroups through an exchange buffer laid out in consumer
-    order (csrc/hip/lstm_seq.hip, coalesced exchange form). ``nets`` = list of (xg, w_hh, hs, cs, gates | None, hx) with
-    hx from :func:`lstm_hx` (one per network, not shared between launches that may run at the same time)."""
+    order (csrc/hip/lstm_seq.hip, coalesced exchange form). ``nets`` = list of (xg, w_hh, hs, cs, gates | None, hx) or
+    (xg, w_hh, hs, cs, gates | None, hx, bias) with hx from :func:`lstm_hx` (one per network, not shared between launches
+    that may run at the same time); ``bias`` ([4H] fp32, gate-interleaved like xg's columns) is added to xg on the fly."""
     assert 1 <= len(nets) <= 2
     _chk(err, torch.int32, "err")
     args = []
-    for xg, w_hh, hs, cs, gates, hx in nets:
+    for net in nets:
+        xg, w_hh, hs, cs, gates, hx = net[:6]
+        bias = net[6] if len(net) > 6 else None
         _chk(xg, torch.float32, "xg"); _chk(w_hh, torch.bfloat16, "w_hh"); _chk(hs, torch.bfloat16, "hs"); _chk(cs, torch.float32, "cs")
         _chk(hx, torch.int64, "hx")
         assert xg.numel() == T * M * 4 * Hd and hs.numel() == (T + 1) * M * Hd and cs.numel() == (T + 1) * M * Hd
         assert w_hh.shape == (4 * Hd, Hd) and (gates is None or gates.numel() == T * M * 4 * Hd) and hx.numel() == 32768
-        args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates), _p(hx)]
+        if bias is not None:
+            _chk(bias, torch.float32, "bias")
+            assert bias.numel() == 4 * Hd
+        args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates), _p(bias), _p(hx)]
     if len(nets) == 1:
-        args += [None] * 6
+        args += [None] * 7
     _ck(native.hip().drl_lstm_seq_fwd_x(*args, len(nets), T, M, Hd, _p(err), _s()), "lstm_seq_fwd_x")
 
 

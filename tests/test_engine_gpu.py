@@ -335,7 +335,12 @@ def test_r2d2_engine_library_gemm_matches_own_kernels(monkeypatch):
         _, cfg, rep, eng = _r2d2_setup(B=16, cap=48, seed=6)
         eng._forward_backward()
         torch.cuda.synchronize()
-        outs.append((eng.on.q.clone(), eng.G.flat.clone(), eng.stats()["loss"], eng.on.xg.clone()))
+        from distributed_rl_amd.engine.r2d2 import defer_xg_bias
+        xg = eng.on.xg.clone()
+        t0, t1 = eng.fwd_bounds[0]
+        if defer_xg_bias((t1 - t0) * eng.B, eng.Hd, eng.persistent_lstm):
+            xg += eng.bsum_on                         # the exchange-form recurrence adds the bias on the fly
+        outs.append((eng.on.q.clone(), eng.G.flat.clone(), eng.stats()["loss"], xg))
     torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-2, atol=2e-2)
     assert outs[0][2] == pytest.approx(outs[1][2], rel=3e-2)
