@@ -50,6 +50,20 @@ __global__ void k_gather_state(const float* __restrict__ src, const int* __restr
     if (dst_bf16) dst_bf16[i] = f2bf(v);
 }
 
+// the stored (h0, c0) of the sampled sequences into the initial-state rows of TWO networks, one launch
+__global__ void k_gather_state2(const float* __restrict__ h0, const float* __restrict__ c0, const int* __restrict__ idx, int B, int H,
+                                bf16_t* __restrict__ hs_a, float* __restrict__ cs_a, bf16_t* __restrict__ hs_b,
+                                float* __restrict__ cs_b) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    int b = i / H, u = i - b * H;
+    const long long o = (long long)idx[b] * H + u;
+    const float h = h0[o], c = c0[o];
+    const bf16_t hb = f2bf(h);
+    hs_a[i] = hb; cs_a[i] = c;
+    if (hs_b) { hs_b[i] = hb; cs_b[i] = c; }
+}
+
 __global__ void k_add2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -71,6 +85,12 @@ DRL_API int drl_seq_offsets(const int* idx, int B, int T, long long frame_bytes,
 DRL_API int drl_gather_state(const float* src, const int* idx, int B, int H, float* dst_f32, void* dst_bf16, hipStream_t s) {
     if (B <= 0 || H <= 0) return -1;
     k_gather_state<<<(B * H + 255) / 256, 256, 0, s>>>(src, idx, B, H, dst_f32, (bf16_t*)dst_bf16);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_gather_state2(const float* h0, const float* c0, const int* idx, int B, int H, void* hs_a, float* cs_a, void* hs_b,
+                              float* cs_b, hipStream_t s) {
+    if (B <= 0 || H <= 0 || !hs_a || !cs_a || (!hs_b) != (!cs_b)) return -1;
+    k_gather_state2<<<(B * H + 255) / 256, 256, 0, s>>>(h0, c0, idx, B, H, (bf16_t*)hs_a, cs_a, (bf16_t*)hs_b, cs_b);
     return (int)hipGetLastError();
 }
 DRL_API int drl_add2(const float* a, const float* b, float* out, int n, hipStream_t s) {

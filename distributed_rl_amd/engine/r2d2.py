@@ -208,8 +208,7 @@ class R2D2Engine:
     # ---- forward of one net over the whole sampled batch ---------------------------------------------------
     def _net_forward(self, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor) -> None:
         r = self.replay
-        H.gather_state(r.h0, r.idx, None, buf.hs[0])
-        H.gather_state(r.c0, r.idx, buf.cs[0], None)
+        H.gather_state2(r.h0, r.c0, r.idx, buf.hs[0], buf.cs[0])
         seq_net_forward(r.frames, r.frame_off, self.T, self.B, self.Hd, wb, wf, buf, bsum, self.persistent_lstm)
 
     def _forward_backward(self) -> None:
@@ -219,16 +218,17 @@ class R2D2Engine:
         # forward. The two nets are STAGGERED, not run side by side: the torso is throughput-bound, the recurrence is
         # latency-bound (32 workgroups), so the target torso runs under the online recurrence and the two recurrences
         # overlap only partly.
-        H.gather_state(r.h0, r.idx, None, self.on.hs[0])
-        H.gather_state(r.c0, r.idx, self.on.cs[0], None)
-        if self.fwd_chunks > 1 and fj.enabled:
+        pipelined = self.fwd_chunks > 1 and fj.enabled
+        if pipelined:                                               # initial state of both networks, one launch
+            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0])
+        else:
+            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0])
+        if pipelined:
             # PIPELINED over time chunks: the torso of chunk k+1 (throughput-bound, all CUs) runs while the recurrences
             # of chunk k (latency-bound, 32 workgroups per net) chase it on two side streams, so the forward costs about
             # one recurrence + one torso chunk instead of two torsos + one recurrence. Measured (64 x 120, MI355X): 4.03 /
             # 3.76 / 3.87 / 4.49 / 4.47 ms per step for 1 / 2 / 4 / 6 / 8 chunks (every chunk restarts the persistent
             # kernel - W_hh slice back into LDS - and the recurrence steps slow down under the torso's memory traffic)
-            H.gather_state(r.h0, r.idx, None, self.tg.hs[0])
-            H.gather_state(r.c0, r.idx, self.tg.cs[0], None)
             dual = self.persistent_lstm and self.dual_lstm
             for st_ in self.fwd_bounds:
                 pl = self.persistent_lstm

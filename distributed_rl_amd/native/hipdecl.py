@@ -50,6 +50,7 @@ SIGS = {
     "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "drl_seq_offsets": [P, I, I, L, P, P],
     "drl_gather_state": [P, P, I, I, P, P, P],
+    "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P],
     "drl_add2": [P, P, P, I, P],
     # conv_bwd.hip
     "drl_col2im": [I, P, P, P, I, P],

@@ -605,5 +605,16 @@ def gather_state(src, idx, dst_f32=None, dst_bf16=None) -> None:
     _ck(native.hip().drl_gather_state(_p(src), _p(idx), idx.numel(), src.shape[-1], _p(dst_f32), _p(dst_bf16), _s()), "gather_state")
 
 
+def gather_state2(h0, c0, idx, hs_a, cs_a, hs_b=None, cs_b=None) -> None:
+    """Stored recurrent state of the sampled sequences -> initial-state rows (h as bf16, c as fp32) of one or two
+    networks, one launch."""
+    _chk(h0, torch.float32, "h0"); _chk(c0, torch.float32, "c0"); _chk(idx, torch.int32, "idx")
+    _chk(hs_a, torch.bfloat16, "hs_a"); _chk(cs_a, torch.float32, "cs_a")
+    if hs_b is not None:
+        _chk(hs_b, torch.bfloat16, "hs_b"); _chk(cs_b, torch.float32, "cs_b")
+    _ck(native.hip().drl_gather_state2(_p(h0), _p(c0), _p(idx), idx.numel(), h0.shape[-1], _p(hs_a), _p(cs_a), _p(hs_b), _p(cs_b),
+                                       _s()), "gather_state2")
+
+
 def add2(a, b, out) -> None:
     _ck(native.hip().drl_add2(_p(a), _p(b), _p(out), a.numel(), _s()), "add2")
