@@ -102,6 +102,11 @@ def main():
              "replay_items_per_gpu": cap, "graph": eng._graphs[0] if eng._graphs else "eager"}
     if dist.world_size > 1:
         extra["grad_all_reduce"] = "direct xGMI kernel (in graph)" if dist.xgmi is not None else "RCCL"
+        try:    # data-parallel sanity: every rank applied the same averaged gradients -> identical parameters everywhere
+            cs = float(eng.P.flat.double().abs().sum().item())
+            extra["dp_params_identical"] = bool(dist.max_scalar(cs) == -dist.max_scalar(-cs))
+        except Exception as e:  # side information only
+            extra["dp_params_identical"] = repr(e)[:100]
 
     # side metrics only on one GPU: at N > 1 nothing after the timed region may put the headline line at risk
     if not args.no_extra and dist.world_size == 1:
