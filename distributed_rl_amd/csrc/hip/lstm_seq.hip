@@ -178,7 +178,7 @@ __device__ __forceinline__ void grid_wait_fl(int* flags, int nwg, int target, in
         int it = 0;
         while (true) {
             const int v = mine ? __hip_atomic_load(flags + threadIdx.x * DRL_LSTM_FLAG_STRIDE, RLX_AGENT) : target;
-            if (__all(v >= target)) break;
+            if (__all((int)((unsigned)v - (unsigned)target) >= 0)) break;          // wrap-safe: flags carry a launch epoch
             if (++it > SPIN_LIMIT) { if (threadIdx.x == 0) { atomicExch(err, 1); *s_dead = 1; } break; }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
     __shared__ int s_dead;
     if (tid == 0) s_dead = 0;
     __syncthreads();
+    // No memset between launches: a flag holds (launch epoch << 12) + steps finished. Every workgroup counts the launches
+    // of this buffer in a word of its own (all of them run in every launch, so the counts agree without communication).
+    int* my_epoch = sync + (NWG + wg) * DRL_LSTM_FLAG_STRIDE;
+    const int base = (int)((unsigned)*my_epoch << 12);
     for (int t = 0; t < T; ++t) {
         float4 xq[4];
         const float* xrow = a.xg + ((size_t)t * M + m) * (4 * HD) + 4 * u0;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) hf[ks] = __builtin_bit_cast(bf16x8, hrow[ks * 4]);
         } else {
-            grid_wait_fl(sync, NWG, t, err, &s_dead);
+            grid_wait_fl(sync, NWG, base + t, err, &s_dead);
             const unsigned base = (t & 1) * SLOT + ld_off;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {                 // one contiguous KB per instruction, sc1 (never an L1 hit)
@@ -281,17 +285,17 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
                 gout[1] = make_uint4(gp[4], gp[5], gp[6], gp[7]);
             }
         }
-        if (t + 1 < T) grid_arrive_fl(sync, wg, t + 1);
+        if (t + 1 < T) grid_arrive_fl(sync, wg, base + t + 1);
     }
+    if (tid == 0) *my_epoch = (int)(((unsigned)base >> 12) + 1u);
 }
 
-// hx0 / hx1: exchange buffers of 256 KB each (lstm_hx); the arrival counter inside is zeroed here.
+// hx0 / hx1: exchange buffers of 256 KB each (lstm_hx), zero when first used; nothing is reset between launches.
 DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, const float* bias0, void* hx0,
                                 const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, const float* bias1, void* hx1, int n_nets,
                                 int T, int M, int H, int* err, hipStream_t s) {
     if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2 || !hx0 || (n_nets == 2 && !hx1)) return -1;
-    if (hipMemsetAsync((uint8_t*)hx0 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
-    if (n_nets == 2 && hipMemsetAsync((uint8_t*)hx1 + HX_SYNC_BYTE_OFFSET, 0, 32 * DRL_LSTM_FLAG_STRIDE * 4, s) != hipSuccess) return -2;
+    if (T >= 4096) return -1;                                  // flags carry the step in 12 bits
     LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, bias0, (bf16_t*)hx0};
     LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, bias1, (bf16_t*)hx1};
     constexpr int LDS = 4 * (512 / 32) * 1024;
