@@ -321,3 +321,148 @@ DRL_API int drl_lstm_seq_fwd(const float* xg0, const void* w0, void* hs0, float*
     kern<<<n_nets * (4 * 512 / 64), 256, LDS, s>>>(a, b, T, M, err);
     return (int)hipGetLastError();
 }
+
+
+// ---- persistent BPTT ------------------------------------------------------------------------------------------------
+// The backward recurrence as ONE launch per time chunk (was: one launch per step, 9.8 us each, a third of the R2D2 step).
+// Same decomposition as the forward: workgroup j owns hidden units [16j, 16j+16), wave w batch rows [16w, 16w+16), a lane
+// 4 consecutive units of one row - for those it keeps dc in registers, reads gates / c / dh_head of the step (plain loads,
+// issued before the wait: they do not depend on the recurrence), and produces the 16 gate gradients dG (bf16, as the
+// weight-gradient GEMMs read them). What it needs from the others is dh_rec[m][own units] = sum_n dG_{t+1}[m][n] W_hh[n][u]:
+// the whole dG of the previous step (64 x 2048 bf16), handed over through an exchange buffer in consumer order
+// ([parity][wave][ks = n/32][lane][8 bf16]: one load instruction = one contiguous KB) exactly like h in the forward, and
+// multiplied with the workgroup's 2048 x 16 column slice of W_hh, which sits in LDS in MFMA-fragment order for the whole
+// launch. K = 2048 is accumulated in one fp32 MFMA accumulator in a fixed order: no atomics, bit-reproducible.
+struct BpttArgs {
+    const bf16_t* dhs;    // [L][M][H]    dL/dh_t from the heads (window index k = t - burn)
+    const bf16_t* gates;  // [L][M][4H]   post-activation gates of the window
+    const float* cs;      // [L+1][M][H]  cs[k] = c_{t-1}, cs[k+1] = c_t
+    bf16_t* dG;           // [L][M][4H]   out: gate gradients
+    const bf16_t* w_hh;   // [4H][H]
+    float* dh_rec;        // [M][H] carry between launches (in unless `first`, out if `carry`)
+    float* dc;            // [M][H] carry
+    uint8_t* bx;          // 2 x 256 KB exchange slots, arrival flags + launch counters at byte 512 K
+};
+#define BX_SYNC_BYTE_OFFSET (512 * 1024)
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int steps, int M, int first, int carry, int* err) {
+    constexpr int NWG = HD / 16, NKS = 4 * HD / 32;              // 32 workgroups, 64 k-steps of 32 gate columns
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // NKS KB: W_hh[:, 16 wg .. +15] in fragment order
+    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g4 = lane >> 4;
+    int* sync = reinterpret_cast<int*>(a.bx + BX_SYNC_BYTE_OFFSET);
+    // fragment (ks, lane (ii, g)) element e = W_hh[ks*32 + g*8 + e][16 wg + ii]: row n of the slice is 32 contiguous bytes
+    for (int n = tid; n < 4 * HD; n += 256) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + 16 * wg);
+        const uint4 lo = src[0], hi = src[1];
+        const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        bf16_t* dst = reinterpret_cast<bf16_t*>(smem) + ((size_t)(n >> 5) * 64 + ((n & 31) >> 3) * 16) * 8 + (n & 7);
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) dst[ii * 8] = (bf16_t)((ii & 1) ? (v[ii >> 1] >> 16) : (v[ii >> 1] & 0xffffu));
+    }
+    __shared__ int s_dead;
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
+    const bool active = wave * 16 < M;
+    const int m = min(wave * 16 + r, M - 1);
+    const int u0 = 16 * wg + 4 * g4;                             // this lane owns units u0 .. u0+3 of row m
+    const size_t e0 = (size_t)m * HD + u0;
+    float dc[4] = {0.f, 0.f, 0.f, 0.f}, rec[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        const float4 c4 = *reinterpret_cast<const float4*>(a.dc + e0), r4 = *reinterpret_cast<const float4*>(a.dh_rec + e0);
+        dc[0] = c4.x; dc[1] = c4.y; dc[2] = c4.z; dc[3] = c4.w;
+        rec[0] = r4.x; rec[1] = r4.y; rec[2] = r4.z; rec[3] = r4.w;
+    }
+    const auto bx_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.bx, 0, 2 * 4 * NKS * 64 * 16, 0x00020000);
+    constexpr unsigned SLOT = 4 * NKS * 64 * 16;                 // 256 KB per parity slot
+    const unsigned ld_off = (unsigned)(((wave * NKS) * 64 + lane) * 16);
+    // this lane's 16 gate columns n = 4 u0 .. 4 u0 + 15 in consumer order: k-step n/32, pieces 2 (g4 & 1) and 2 (g4 & 1) + 1
+    const unsigned st_off = (unsigned)((((wave * NKS + (u0 >> 3)) * 64 + (2 * (g4 & 1)) * 16 + r) * 8) * sizeof(bf16_t));
+    int* my_epoch = sync + (NWG + wg) * DRL_LSTM_FLAG_STRIDE;
+    const int base = (int)((unsigned)*my_epoch << 12);
+    // dh_rec of this lane's units from the dG all workgroups published for `stamp` steps
+    auto recurrent = [&](int stamp) {
+        grid_wait_fl(sync, NWG, base + stamp, err, &s_dead);
+        const unsigned b0 = (stamp & 1) * SLOT + ld_off;
+        bf16x8 gf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc, b0 + ks * 1024, 0, 16);
+            gf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + ((size_t)ks * 64 + lane) * 16);
+            acc = mfma16_(wf, gf[ks], acc);
+        }
+        rec[0] = acc[0]; rec[1] = acc[1]; rec[2] = acc[2]; rec[3] = acc[3];
+    };
+    for (int s = 0; s < steps; ++s) {
+        const int k = k_hi - s;
+        const size_t e = (size_t)k * M * HD + e0;
+        // inputs of the pointwise part: independent of the recurrence, in flight while this workgroup waits
+        const uint2 v_dh = *reinterpret_cast<const uint2*>(a.dhs + e);
+        const uint4 v_g0 = *reinterpret_cast<const uint4*>(a.gates + e * 4), v_g1 = *reinterpret_cast<const uint4*>(a.gates + e * 4 + 8);
+        const float4 v_ct = *reinterpret_cast<const float4*>(a.cs + e + (size_t)M * HD), v_cp = *reinterpret_cast<const float4*>(a.cs + e);
+        if (s > 0) recurrent(s);
+        const float ct[4] = {v_ct.x, v_ct.y, v_ct.z, v_ct.w}, cp[4] = {v_cp.x, v_cp.y, v_cp.z, v_cp.w};
+        const uint32_t gw[8] = {v_g0.x, v_g0.y, v_g0.z, v_g0.w, v_g1.x, v_g1.y, v_g1.z, v_g1.w};
+        const float dhh[4] = {__uint_as_float(v_dh.x << 16), __uint_as_float(v_dh.x & 0xffff0000u),
+                              __uint_as_float(v_dh.y << 16), __uint_as_float(v_dh.y & 0xffff0000u)};
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dh = rec[q] + dhh[q];
+            const float ig = __uint_as_float(gw[2 * q] << 16), fg = __uint_as_float(gw[2 * q] & 0xffff0000u);
+            const float gg = __uint_as_float(gw[2 * q + 1] << 16), og = __uint_as_float(gw[2 * q + 1] & 0xffff0000u);
+            const float tc = 2.0f / (1.0f + __expf(-2.0f * ct[q])) - 1.0f;
+            const float dcell = dh * og * (1.0f - tc * tc) + dc[q];
+            const float d_o = dh * tc * og * (1.0f - og);
+            const float d_i = dcell * gg * ig * (1.0f - ig);
+            const float d_g = dcell * ig * (1.0f - gg * gg);
+            const float d_f = dcell * cp[q] * fg * (1.0f - fg);
+            o[2 * q] = pack_bf2(d_i, d_f);
+            o[2 * q + 1] = pack_bf2(d_g, d_o);
+            dc[q] = dcell * fg;
+        }
+        const bool more = s + 1 < steps || carry;
+        if (active) {
+            if (more) {                                            // the hand-off first: it is what the others wait for
+                u64_t* x = reinterpret_cast<u64_t*>(a.bx + ((s + 1) & 1) * SLOT + st_off);
+                __hip_atomic_store(x, (u64_t)o[0] | ((u64_t)o[1] << 32), RLX_AGENT);
+                __hip_atomic_store(x + 1, (u64_t)o[2] | ((u64_t)o[3] << 32), RLX_AGENT);
+                __hip_atomic_store(x + 32, (u64_t)o[4] | ((u64_t)o[5] << 32), RLX_AGENT);      // next piece: 16 lanes x 16 B on
+                __hip_atomic_store(x + 33, (u64_t)o[6] | ((u64_t)o[7] << 32), RLX_AGENT);
+            }
+            uint4* gout = reinterpret_cast<uint4*>(a.dG + e * 4);
+            gout[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            gout[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+        if (more) grid_arrive_fl(sync, wg, base + s + 1);
+    }
+    if (carry) {                                                   // state for the launch that continues the chain
+        recurrent(steps);
+        if (active) {
+            *reinterpret_cast<float4*>(a.dh_rec + e0) = make_float4(rec[0], rec[1], rec[2], rec[3]);
+            *reinterpret_cast<float4*>(a.dc + e0) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+        }
+    }
+    if (tid == 0) *my_epoch = (int)(((unsigned)base >> 12) + 1u);
+}
+
+// Window steps k_hi, k_hi - 1, ..., k_hi - steps + 1 (k = t - burn). first: the chain starts here (dh_rec = dc = 0);
+// carry: another launch continues below k_hi - steps + 1 (dh_rec / dc are written for it). bx: 768 KB scratch, zero when
+// first used. gates / cs are the window parts of the forward buffers (cs has one more row than gates).
+DRL_API int drl_lstm_bptt(const void* dhs, const void* gates, const float* cs, void* dG, const void* w_hh, float* dh_rec, float* dc,
+                          void* bx, int k_hi, int steps, int M, int H, int first, int carry, int* err, hipStream_t s) {
+    if (H != 512 || M <= 0 || M > 64 || (M & 15) || steps <= 0 || steps >= 4095 || k_hi - steps + 1 < 0) return -1;
+    BpttArgs a{(const bf16_t*)dhs, (const bf16_t*)gates, cs, (bf16_t*)dG, (const bf16_t*)w_hh, dh_rec, dc, (uint8_t*)bx};
+    constexpr int LDS = (4 * 512 / 32) * 1024;
+    auto kern = k_lstm_bptt<512>;
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+    (void)once;
+    kern<<<512 / 16, 256, LDS, s>>>(a, k_hi, steps, M, first, carry, err);
+    return (int)hipGetLastError();
+}

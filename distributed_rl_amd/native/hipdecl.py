@@ -45,6 +45,7 @@ SIGS = {
     # lstm_seq.hip
     "drl_lstm_seq_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P],
     "drl_lstm_seq_fwd_x": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P],
+    "drl_lstm_bptt": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P],
     # lstm.hip
     "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
     "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],

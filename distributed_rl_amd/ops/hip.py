@@ -566,6 +566,26 @@ def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
     _ck(native.hip().drl_lstm_seq_fwd_x(*args, len(nets), T, M, Hd, _p(err), _s()), "lstm_seq_fwd_x")
 
 
+def lstm_bx(device) -> torch.Tensor:
+    """Scratch of :func:`lstm_bptt`: 768 KB (two 256 KB parity slots of gate gradients + arrival flags)."""
+    return torch.zeros(98304, dtype=torch.int64, device=device)
+
+
+def lstm_bptt(dhs, gates, cs, dG, w_hh, dh_rec, dc, bx, err, k_hi: int, steps: int, first: bool, carry: bool) -> None:
+    """Persistent BPTT (csrc/hip/lstm_seq.hip k_lstm_bptt): window steps k_hi .. k_hi - steps + 1 in ONE launch.
+    dhs [L,M,H] bf16 (dL/dh from the heads), gates [L,M,4H] bf16, cs [L+1,M,H] f32 (cs[k] = c before step k), dG [L,M,4H]
+    bf16 out, w_hh [4H,H] bf16; dh_rec / dc [M,H] f32 carry the chain between launches (``first``: start from zero,
+    ``carry``: write them for the launch that continues)."""
+    L, M, Hd = dhs.shape
+    _chk(dhs, torch.bfloat16, "dhs"); _chk(gates, torch.bfloat16, "gates"); _chk(cs, torch.float32, "cs"); _chk(dG, torch.bfloat16, "dG")
+    _chk(w_hh, torch.bfloat16, "w_hh"); _chk(dh_rec, torch.float32, "dh_rec"); _chk(dc, torch.float32, "dc")
+    _chk(bx, torch.int64, "bx"); _chk(err, torch.int32, "err")
+    assert gates.shape == (L, M, 4 * Hd) and cs.shape == (L + 1, M, Hd) and dG.shape == (L, M, 4 * Hd) and w_hh.shape == (4 * Hd, Hd)
+    assert dh_rec.shape == (M, Hd) and dc.shape == (M, Hd) and bx.numel() >= 98304 and 0 <= k_hi - steps + 1 and k_hi < L
+    _ck(native.hip().drl_lstm_bptt(_p(dhs), _p(gates), _p(cs), _p(dG), _p(w_hh), _p(dh_rec), _p(dc), _p(bx), k_hi, steps, M, Hd,
+                                   int(first), int(carry), _p(err), _s()), "lstm_bptt")
+
+
 def lstm_seq_supported(M: int, Hd: int) -> bool:
     return Hd == 512 and 0 < M <= 64 and M % 16 == 0
 

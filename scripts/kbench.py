@@ -224,6 +224,15 @@ def main():
             t = Tb - 1 - s_
             H.lstm_bwd_step(dhs_b[t], R3[s_ % 3], R3[(s_ + 1) % 3], R3[(s_ + 2) % 3], DC2[s_ % 2], DC2[(s_ + 1) % 2], gts_b[t],
                             css_b[t + 1], css_b[t], dG_b[t], whh)
+    bx_b, rec_b, dc_b = H.lstm_bx(DEV), torch.zeros(64, 512, device=DEV), torch.zeros(64, 512, device=DEV)
+    cases["lstm_bptt80_persistent"] = (lambda: H.lstm_bptt(dhs_b, gts_b, css_b, dG_b, whh, rec_b, dc_b, bx_b, err, k_hi=Tb - 1, steps=Tb,
+                                                           first=True, carry=False), 2 * 64 * 2048 * 512 * Tb, 0)
+
+    def bptt_two_chunks():
+        H.lstm_bptt(dhs_b, gts_b, css_b, dG_b, whh, rec_b, dc_b, bx_b, err, k_hi=Tb - 1, steps=Tb // 2, first=True, carry=True)
+        H.lstm_bptt(dhs_b, gts_b, css_b, dG_b, whh, rec_b, dc_b, bx_b, err, k_hi=Tb - 1 - Tb // 2, steps=Tb - Tb // 2, first=False,
+                    carry=False)
+    cases["lstm_bptt80_persistent_2chunks"] = (bptt_two_chunks, 2 * 64 * 2048 * 512 * Tb, 0)
     cases["lstm_bptt80_two_launches"] = (bptt_two, 2 * 64 * 2048 * 512 * Tb, 0)
     cases["lstm_bptt80_fused_step"] = (bptt_fused, 2 * 64 * 2048 * 512 * Tb, 0)
     print("%-18s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))

@@ -324,6 +324,26 @@ def test_r2d2_engine_persistent_lstm_matches_step_launches():
     assert float((outs[0][2] - outs[1][2]).norm() / gn1) < 5e-2 and float(gn0) > 0
 
 
+def test_r2d2_engine_persistent_bptt_matches_step_launches():
+    """B = 16 takes the persistent BPTT kernel (one launch per backward chunk); DRL_PERSISTENT_BPTT=0 the one-launch-per-
+    step chain. Same forward, so the whole gradient must agree tightly (bf16 gate gradients in both, fp32 accumulation)."""
+    import os
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["DRL_PERSISTENT_BPTT"] = flag
+        try:
+            _, cfg, rep, eng = _r2d2_setup(B=16, cap=48, seed=9)
+        finally:
+            os.environ.pop("DRL_PERSISTENT_BPTT", None)
+        assert eng.persistent_bptt == (flag == "1")
+        eng._forward_backward()
+        torch.cuda.synchronize()
+        eng.stats()                                   # raises if a wait inside the persistent kernels timed out
+        outs.append((eng.dG.float().clone(), eng.G.flat.clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=3e-2, atol=1e-5)
+    assert float((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()) < 1e-2 and float(outs[0][1].norm()) > 0
+
+
 def test_r2d2_engine_library_gemm_matches_own_kernels(monkeypatch):
     """The big plain products of the R2D2 step go to hipBLASLt (ops.hip.lib_gemm); forced on at test size they must
     give the same Q values, loss and gradient as the hand-written GEMM (both accumulate in fp32)."""

@@ -771,3 +771,33 @@ def test_lstm_bwd_step_fused_matches_two_launches(hip, M):
     torch.testing.assert_close(dG1.float(), dG0.float(), rtol=2e-2, atol=1e-5)
     torch.testing.assert_close(R[steps % 3], dh_rec, rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(DC[steps % 2], dc, rtol=2e-3, atol=1e-4)          # fed by dh_rec: float-atomics order
+
+
+@pytest.mark.parametrize("M", [16, 64])
+def test_lstm_bptt_persistent_matches_step_launches(hip, M):
+    """Persistent BPTT (one launch per chunk, two chained launches here) against the one-launch-per-step kernel."""
+    H = hip
+    Hd, L = 512, 7
+    g = torch.Generator().manual_seed(900 + M)
+    w = bf(torch.randn(4 * Hd, Hd, generator=g) * 0.05).to(DEV)
+    dhs = bf(torch.randn(L, M, Hd, generator=g) * 0.1).to(DEV)
+    gates = bf(torch.rand(L, M, 4 * Hd, generator=g) * 0.9 + 0.05).to(DEV)
+    cs = (torch.randn(L + 1, M, Hd, generator=g) * 0.5).to(DEV)
+    # reference: the per-step kernel with its rotating buffers
+    R, DC = torch.zeros(3, M, Hd, device=DEV), torch.zeros(2, M, Hd, device=DEV)
+    dG_ref = torch.zeros(L, M, 4 * Hd, dtype=torch.bfloat16, device=DEV)
+    for s_, k in enumerate(range(L - 1, -1, -1)):
+        if k > 0:
+            H.lstm_bwd_step(dhs[k], R[s_ % 3], R[(s_ + 1) % 3], R[(s_ + 2) % 3], DC[s_ % 2], DC[(s_ + 1) % 2], gates[k], cs[k + 1],
+                            cs[k], dG_ref[k], w)
+        else:
+            H.lstm_bwd_point(dhs[k], R[s_ % 3], DC[s_ % 2], gates[k], cs[k + 1], cs[k], dG_ref[k])
+    dG = torch.zeros_like(dG_ref)
+    rec, dc = torch.zeros(M, Hd, device=DEV), torch.zeros(M, Hd, device=DEV)
+    bx, err = H.lstm_bx(DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    for rep in range(2):                                            # twice: the scratch is reused across launches (epochs)
+        H.lstm_bptt(dhs, gates, cs, dG, w, rec, dc, bx, err, k_hi=L - 1, steps=4, first=True, carry=True)
+        H.lstm_bptt(dhs, gates, cs, dG, w, rec, dc, bx, err, k_hi=L - 5, steps=3, first=False, carry=False)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    torch.testing.assert_close(dG.float().cpu(), dG_ref.float().cpu(), rtol=3e-2, atol=2e-4)
