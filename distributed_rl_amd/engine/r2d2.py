@@ -33,6 +33,11 @@ from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
 
 
+def _os_environ_get(name: str):
+    import os
+    return os.environ.get(name)
+
+
 class SeqNetBuffers:
     def __init__(self, T: int, B: int, Hd: int, n_action: int, device, save_gates: bool):
         bf = dict(dtype=torch.bfloat16, device=device)
@@ -296,6 +301,15 @@ class R2D2Engine:
         w_hh = Pb.view("lstm.w_hh")
         csz = (L + self.bwd_chunks - 1) // self.bwd_chunks
         starts = set(range(0, L, csz))
+        if self.persistent_bptt and self.bwd_chunks == 2:
+            # the persistent chain is faster than the torso backward it feeds: a smaller newest chunk starts the torso
+            # earlier (2.49 / 2.44 / 2.43 / 2.45 ms for a cut at window step 64 / 56 / 48 / 40 of 80; more cuts: 2.59-2.61)
+            starts = {0, (3 * L) // 5}
+        cuts_env = _os_environ_get("DRL_BWD_CUTS")                 # explicit chunk starts in window steps, e.g. "48,64"
+        if cuts_env:
+            starts = {0} | {int(c) for c in cuts_env.split(",") if c.strip() and 0 < int(c) < L}
+        order = sorted(starts)
+        end_of = {k0: (order[i + 1] if i + 1 < len(order) else L) for i, k0 in enumerate(order)}
         fused_step = self.fused_bptt
         if self.persistent_bptt:
             k_hi = L - 1
@@ -303,7 +317,7 @@ class R2D2Engine:
                 H.lstm_bptt(self.dhs, on.gates[burn:T], on.cs[burn:T + 1], self.dG, w_hh, self.bptt_rec, self.bptt_dc, self.bx,
                             self.bptt_err, k_hi=k_hi, steps=k_hi - k0 + 1, first=i == 0, carry=k0 > 0)
                 with fj.fork(1):
-                    self._torso_backward(k0, min(L, k0 + csz))
+                    self._torso_backward(k0, end_of[k0])
                 k_hi = k0 - 1
         elif fused_step:
             R, DC = self.dh_rec3, self.dc2
@@ -325,7 +339,7 @@ class R2D2Engine:
                     H.gemm(H.NN, self.dG[k], w_hh, self.dh_rec, B, Hd, 4 * Hd, flags=H.EPI_OUT_F32 | H.EPI_ATOMIC, splits=8, big=5)
             if k in starts:
                 with fj.fork(1):
-                    self._torso_backward(k, min(L, k + csz))
+                    self._torso_backward(k, end_of[k])
         dG = self.dG.view(NB, 4 * Hd)
         with fj.fork(0):                                            # LSTM weight gradients: need the whole window
             H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
