@@ -187,6 +187,7 @@ class R2D2Engine:
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
         self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1" if H.LSTM_XCHG else "0") != "0"
+        self.dual_heads = _os.environ.get("DRL_DUAL_HEADS", "1") != "0"   # FC + head of both networks per launch (needs dual_lstm)
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # the whole backward recurrence of a time chunk as ONE persistent launch (4.5 us per step instead of ~10)
         self.persistent_bptt = H.lstm_seq_supported(self.B, self.Hd) and _os.environ.get("DRL_PERSISTENT_BPTT", "1") != "0"
@@ -266,10 +267,21 @@ class R2D2Engine:
                 else:
                     with fj.fork(2):
                         seq_recurrence(T, B, Hd, self.Tb, self.tg, pl, steps=st_, bsum=self.bsum_tg)
-            with fj.fork(0):
-                seq_heads(T, B, Hd, self.Pb, self.P, self.on)
-            with fj.fork(2 if not dual else 0):
-                seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
+            if dual and self.dual_heads:
+                # both recurrences ended in the same launch: FC + dueling head of both networks as two launches, not four
+                with fj.fork(0):
+                    N_ = T * B
+                    H.gemm_nt_dual(self.on.hs[1:].view(N_, Hd), self.Pb.view("fc1.w"), self.P.view("fc1.b"), self.on.h2,
+                                   self.tg.hs[1:].view(N_, Hd), self.Tb.view("fc1.w"), self.Tg.view("fc1.b"), self.tg.h2,
+                                   1024, Hd, flags=H.EPI_RELU)
+                    H.head_fwd_dual(self.on.h2, self.Pb.view("adv2.w"), None, self.Pb.view("val2.w"), self.P.view("val2.b"),
+                                    self.on.q, self.tg.h2, self.Tb.view("adv2.w"), None, self.Tb.view("val2.w"),
+                                    self.Tg.view("val2.b"), self.tg.q)
+            else:
+                with fj.fork(0):
+                    seq_heads(T, B, Hd, self.Pb, self.P, self.on)
+                with fj.fork(2 if not dual else 0):
+                    seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
         else:
             seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on,
                               persistent=self.persistent_lstm)
