@@ -67,6 +67,23 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
     return smem[16];
 }
 
+// Backward of one LSTM unit at one time step, shared by the BPTT kernels (lstm.hip, gemm.hip k_lstm_bwd_step,
+// lstm_seq.hip k_lstm_bptt). g_if / g_go = the saved post-activation gates packed as bf16 pairs (i, f) and (g, o);
+// dh = dL/dh_t (heads + recurrent part), dc = dL/dc_t carried from step t+1 (in) -> dL/dc_{t-1} (out).
+// Returns the four gate gradients packed the same way.
+__device__ __forceinline__ uint2 lstm_bwd_unit(float dh, float& dc, uint32_t g_if, uint32_t g_go, float c_t, float c_prev) {
+    const float ig = __uint_as_float(g_if << 16), fg = __uint_as_float(g_if & 0xffff0000u);
+    const float gg = __uint_as_float(g_go << 16), og = __uint_as_float(g_go & 0xffff0000u);
+    const float tc = 2.0f / (1.0f + __expf(-2.0f * c_t)) - 1.0f;
+    const float dcell = dh * og * (1.0f - tc * tc) + dc;
+    const float d_o = dh * tc * og * (1.0f - og);
+    const float d_i = dcell * gg * ig * (1.0f - ig);
+    const float d_g = dcell * ig * (1.0f - gg * gg);
+    const float d_f = dcell * c_prev * fg * (1.0f - fg);
+    dc = dcell * fg;
+    return make_uint2(pack_bf2(d_i, d_f), pack_bf2(d_g, d_o));
+}
+
 // Philox-4x32-10 counter RNG (device-side ε-greedy and PER sampling; no host RNG on the hot path)
 struct Philox {
     uint32_t k0, k1;

@@ -1325,18 +1325,10 @@ __global__ __launch_bounds__(NTHREADS) void k_lstm_bwd_step(const bf16_t* __rest
         float dcn[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float dh = rec[q] + dhh[q];
-            const float ig = __uint_as_float(gw[2 * q] << 16), fg = __uint_as_float(gw[2 * q] & 0xffff0000u);
-            const float gg = __uint_as_float(gw[2 * q + 1] << 16), og = __uint_as_float(gw[2 * q + 1] & 0xffff0000u);
-            const float tc = 2.0f / (1.0f + __expf(-2.0f * ct[q])) - 1.0f;
-            const float dcell = dh * og * (1.0f - tc * tc) + dcv[q];
-            const float d_o = dh * tc * og * (1.0f - og);
-            const float d_i = dcell * gg * ig * (1.0f - ig);
-            const float d_g = dcell * ig * (1.0f - gg * gg);
-            const float d_f = dcell * cp[q] * fg * (1.0f - fg);
-            o[2 * q] = live ? pack_bf2(d_i, d_f) : 0u;
-            o[2 * q + 1] = live ? pack_bf2(d_g, d_o) : 0u;
-            dcn[q] = dcell * fg;
+            dcn[q] = dcv[q];
+            const uint2 dg = lstm_bwd_unit(rec[q] + dhh[q], dcn[q], gw[2 * q], gw[2 * q + 1], ct[q], cp[q]);
+            o[2 * q] = live ? dg.x : 0u;
+            o[2 * q + 1] = live ? dg.y : 0u;
         }
         if (j == 0 && live) {
             *reinterpret_cast<float4*>(dc_out + e) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);

@@ -19,16 +19,10 @@ __global__ __launch_bounds__(256) void k_lstm_bwd_point(const bf16_t* __restrict
     dh_rec[i] = 0.f;
     if (dh_head) dh += bf2f(dh_head[i]);
     const uint2 gw = *reinterpret_cast<const uint2*>(gates + ((long long)b * H + u) * 4);
-    const float ig = __uint_as_float(gw.x << 16), fg = __uint_as_float(gw.x & 0xffff0000u);
-    const float gg = __uint_as_float(gw.y << 16), og = __uint_as_float(gw.y & 0xffff0000u);
-    const float tc = 2.0f / (1.0f + __expf(-2.0f * c_t[i])) - 1.0f;
-    const float dcell = dh * og * (1.0f - tc * tc) + dc[i];
-    const float d_o = dh * tc * og * (1.0f - og);
-    const float d_i = dcell * gg * ig * (1.0f - ig);
-    const float d_g = dcell * ig * (1.0f - gg * gg);
-    const float d_f = dcell * c_prev[i] * fg * (1.0f - fg);
-    dc[i] = dcell * fg;
-    *reinterpret_cast<uint2*>(dgates + ((long long)b * H + u) * 4) = make_uint2(pack_bf2(d_i, d_f), pack_bf2(d_g, d_o));
+    float dcv = dc[i];
+    const uint2 dg = lstm_bwd_unit(dh, dcv, gw.x, gw.y, c_t[i], c_prev[i]);
+    dc[i] = dcv;
+    *reinterpret_cast<uint2*>(dgates + ((long long)b * H + u) * 4) = dg;
 }
 
 // frame byte offsets of a sampled sequence batch, time-major: off[t*B + b] = (idx[b]*T + t) * frame_bytes

@@ -414,18 +414,9 @@ __global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int ste
         uint32_t o[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float dh = rec[q] + dhh[q];
-            const float ig = __uint_as_float(gw[2 * q] << 16), fg = __uint_as_float(gw[2 * q] & 0xffff0000u);
-            const float gg = __uint_as_float(gw[2 * q + 1] << 16), og = __uint_as_float(gw[2 * q + 1] & 0xffff0000u);
-            const float tc = 2.0f / (1.0f + __expf(-2.0f * ct[q])) - 1.0f;
-            const float dcell = dh * og * (1.0f - tc * tc) + dc[q];
-            const float d_o = dh * tc * og * (1.0f - og);
-            const float d_i = dcell * gg * ig * (1.0f - ig);
-            const float d_g = dcell * ig * (1.0f - gg * gg);
-            const float d_f = dcell * cp[q] * fg * (1.0f - fg);
-            o[2 * q] = pack_bf2(d_i, d_f);
-            o[2 * q + 1] = pack_bf2(d_g, d_o);
-            dc[q] = dcell * fg;
+            const uint2 dg = lstm_bwd_unit(rec[q] + dhh[q], dc[q], gw[2 * q], gw[2 * q + 1], ct[q], cp[q]);
+            o[2 * q] = dg.x;
+            o[2 * q + 1] = dg.y;
         }
         const bool more = s + 1 < steps || carry;
         if (active) {
