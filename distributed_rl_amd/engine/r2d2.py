@@ -87,6 +87,31 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
         H.gemm(H.NT, a3, wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
 
 
+def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
+                           steps: Tuple[int, int], persistent: bool) -> None:
+    """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target), each conv layer as one
+    launch (the second network's read of a frame finds it in the Infinity Cache). net = (wb, wf, buf, bsum)."""
+    t0, t1 = steps
+    r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
+    fo = frame_off[r0:r1]
+    (wb1, wf1, b1, bs1), (wb2, wf2, b2, bs2) = net1, net2
+    H.conv_fwd_dual(1, frames, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], None, n, wb2.view("conv1.w"),
+                    wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
+    for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
+        H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
+                        getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1])
+    for wb, wf, buf, bsum in (net1, net2):
+        if t0 == 0:
+            H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
+        xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
+        if H.use_lib_gemm(n, 4 * Hd, 3136):
+            H.lib_gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg)
+            if not defer_xg_bias(n, Hd, persistent):
+                xg.add_(bsum)
+        else:
+            H.gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
+
+
 def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, persistent: bool,
                    steps: Optional[Tuple[int, int]] = None, bsum: Optional[torch.Tensor] = None) -> None:
     """The recurrence over time steps ``steps`` (default: all T) from the state in buf.hs[t0] / buf.cs[t0]: one persistent
@@ -187,6 +212,7 @@ class R2D2Engine:
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
         self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1" if H.LSTM_XCHG else "0") != "0"
+        self.dual_torso = _os.environ.get("DRL_DUAL_TORSO", "1") != "0"   # conv layers of both networks per launch (same frames)
         self.dual_heads = _os.environ.get("DRL_DUAL_HEADS", "1") != "0"   # FC + head of both networks per launch (needs dual_lstm)
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
         # the whole backward recurrence of a time chunk as ONE persistent launch (4.5 us per step instead of ~10)
@@ -245,11 +271,17 @@ class R2D2Engine:
             dual = self.persistent_lstm and self.dual_lstm
             for st_ in self.fwd_bounds:
                 pl = self.persistent_lstm
-                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_, persistent=pl)
-                if not dual:
-                    with fj.fork(0):
-                        seq_recurrence(T, B, Hd, self.Pb, self.on, pl, steps=st_, bsum=self.bsum_on)
-                seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_, persistent=pl)
+                if dual and self.dual_torso:
+                    seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
+                                           (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl)
+                else:
+                    seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
+                                      persistent=pl)
+                    if not dual:
+                        with fj.fork(0):
+                            seq_recurrence(T, B, Hd, self.Pb, self.on, pl, steps=st_, bsum=self.bsum_on)
+                    seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_,
+                                      persistent=pl)
                 if dual:
                     # both recurrences of the chunk in ONE persistent launch (64 workgroups): 685 us for 120 steps of two
                     # nets against 655 us for one, so the second network rides along almost for free
