@@ -230,6 +230,11 @@ class R2D2Engine:
             n_ = max(1, int(fc))
             csz_ = (self.T + n_ - 1) // n_
             cuts = list(range(csz_, self.T, csz_))
+            if n_ == 2 and self.T >= 10:
+                # the torso, not the recurrence, bounds the pipelined forward since the recurrence got faster: a larger first
+                # chunk leaves a shorter recurrence after the last torso (2.36 / 2.33 / 2.33 / 2.37 / 2.43 ms per step for a
+                # cut at 60 / 72 / 80 / 90 / 100 of 120)
+                cuts = [(3 * self.T) // 5]
         self.fwd_bounds = list(zip([0] + cuts, cuts + [self.T]))
         self.fwd_chunks = len(self.fwd_bounds)
         self.world = dist.world_size if dist is not None else 1
