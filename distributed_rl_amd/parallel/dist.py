@@ -123,6 +123,7 @@ class Dist:
         g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
         cut = (numel // 41) // 64 * 64
         ar.set_timeout(1.0)                                     # a broken path must fail fast, not look like a hang
+        good = True
         for k in range(3):
             ar.flat.zero_()
             ar.flat[:numel].normal_(generator=g)
@@ -135,10 +136,10 @@ class Dist:
                 ar.all_reduce(ar.flat[cut:numel], channel=0)
                 ar.all_reduce(ar.flat[:cut], channel=1)
             torch.cuda.synchronize(self.device)
-            if ar.error() != 0 or not torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4):
-                return False
+            # no early return: the loop contains collectives of the process group, every rank takes all of them
+            good = good and ar.error() == 0 and bool(torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4))
         ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
-        return True
+        return good
 
     def check_health(self) -> None:
         """Raises if a poll of the direct all-reduce timed out since the last call (a peer did not arrive). Synchronises."""

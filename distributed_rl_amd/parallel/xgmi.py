@@ -47,26 +47,50 @@ class XgmiAllReduce:
         self.rank, self.world, self.device = rank, world, device
         self.cap = (numel + 63) // 64 * 64
         self._ctx = ctypes.c_void_p()
+        self.flat, self._base = None, 0
+        # Set-up is a sequence of COLLECTIVE steps (handle exchange, agreement). A rank whose local part fails must still
+        # take every collective step, or its peers would pair their next collective with a different one of ours: failures
+        # are recorded, agreed on, and raised on ALL ranks together afterwards.
+        ok, why = True, ""
+        mine = ctypes.create_string_buffer(128)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", "") + "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "")
         with torch.cuda.device(self.device):
-            self._ck(self.lib.drl_xar_create(rank, world, self.cap, n_blocks, timeout_s, ctypes.byref(self._ctx)), "create")
-            mine = ctypes.create_string_buffer(128)
-            self._ck(self.lib.drl_xar_handles(self._ctx, mine), "handles")
+            try:
+                self._ck(self.lib.drl_xar_create(rank, world, self.cap, n_blocks, timeout_s, ctypes.byref(self._ctx)), "create")
+                self._ck(self.lib.drl_xar_handles(self._ctx, mine), "handles")
+            except Exception as e:                                 # noqa: BLE001
+                ok, why = False, repr(e)
             every = [None] * world
-            # the peer's device ordinal is only meaningful when both processes enumerate the same devices
-            vis = os.environ.get("HIP_VISIBLE_DEVICES", "") + "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "")
             if world > 1:
-                td.all_gather_object(every, (bytes(mine.raw), self.device.index, vis), group=group)
-            for p in range(world):
-                if p != rank:
-                    handles, dev_p, vis_p = every[p]
-                    self._ck(self.lib.drl_xar_open(self._ctx, p, ctypes.c_char_p(handles), dev_p if vis_p == vis else -1),
-                             "open(peer %d)" % p)
-            ptr = self.lib.drl_xar_data_ptr(self._ctx)
-            self.flat = torch.as_tensor(_DevMem(ptr, self.cap, self), device=self.device)
-        assert self.flat.data_ptr() == ptr and self.flat.dtype == torch.float32
-        self._base = ptr
-        if world > 1:
-            td.barrier(group=group)                      # nobody launches before every peer has mapped every buffer
+                td.all_gather_object(every, (bytes(mine.raw) if ok else None, self.device.index, vis), group=group)
+            if ok:
+                try:
+                    for p in range(world):
+                        if p == rank:
+                            continue
+                        handles, dev_p, vis_p = every[p]
+                        if handles is None:
+                            raise RuntimeError("peer %d could not allocate its buffers" % p)
+                        # the peer's device ordinal is only meaningful when both processes enumerate the same devices
+                        self._ck(self.lib.drl_xar_open(self._ctx, p, ctypes.c_char_p(handles), dev_p if vis_p == vis else -1),
+                                 "open(peer %d)" % p)
+                    ptr = self.lib.drl_xar_data_ptr(self._ctx)
+                    self.flat = torch.as_tensor(_DevMem(ptr, self.cap, self), device=self.device)
+                    if self.flat.data_ptr() != ptr or self.flat.dtype != torch.float32:
+                        raise RuntimeError("could not wrap the communication buffer as a tensor")
+                    self._base = ptr
+                except Exception as e:                             # noqa: BLE001
+                    ok, why = False, repr(e)
+            if world > 1:
+                # agreement; it is also the barrier "nobody launches before every peer has mapped every buffer"
+                votes = [None] * world
+                td.all_gather_object(votes, (ok, why), group=group)
+                bad = [(p, w) for p, (o, w) in enumerate(votes) if not o]
+                if bad:
+                    ok, why = False, "rank %d: %s" % bad[0]
+        if not ok:
+            self.close()
+            raise RuntimeError("xgmi all-reduce set-up failed (%s)" % why)
 
     def _ck(self, rc: int, what: str) -> None:
         if rc != 0:
