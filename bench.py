@@ -102,6 +102,8 @@ def main():
              "replay_items_per_gpu": cap, "graph": eng._graphs[0] if eng._graphs else "eager"}
     if dist.world_size > 1:
         extra["grad_all_reduce"] = "direct xGMI kernel (in graph)" if dist.xgmi is not None else "RCCL"
+        if dist.all_reduce_us is not None:                 # stand-alone us per 13 MB all-reduce measured at start-up
+            extra["grad_all_reduce_us"] = dist.all_reduce_us
         try:    # data-parallel sanity: every rank applied the same averaged gradients -> identical parameters everywhere
             cs = float(eng.P.flat.double().abs().sum().item())
             extra["dp_params_identical"] = bool(dist.max_scalar(cs) == -dist.max_scalar(-cs))

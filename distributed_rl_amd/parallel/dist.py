@@ -57,6 +57,7 @@ class Dist:
         # DRL_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
         self.enabled = self.world_size > 1 or os.environ.get("DRL_FORCE_DIST") == "1"
         self.xgmi = None                                       # direct xGMI all-reduce, see grad_buffer()
+        self.all_reduce_us = None                              # {"direct_xgmi": us, "process_group": us} measured by grad_buffer()
         if self.enabled and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -91,6 +92,12 @@ class Dist:
             ar = XgmiAllReduce(numel, self.device, self.rank, self.world_size,
                                n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")))
             ok = self._verify_xgmi(ar, numel)
+            # both paths are correct here: keep the direct kernel unless the process group's all-reduce is clearly faster on
+            # THIS node (every rank times both - collective calls - and the slowest rank's numbers decide)
+            t_x, t_pg = self._time_all_reduces(ar, numel)
+            self.all_reduce_us = {"direct_xgmi": round(t_x, 1), "process_group": round(t_pg, 1)}
+            if ok and mode != "1" and t_x > 1.25 * t_pg:
+                ok, why = False, "slower than the process group here: %.0f vs %.0f us" % (t_x, t_pg)
         except Exception as e:                                  # noqa: BLE001 - any failure means "use RCCL"
             ok, why = False, repr(e)
         try:                                                    # same verdict on every rank
@@ -140,6 +147,24 @@ class Dist:
             good = good and ar.error() == 0 and bool(torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4))
         ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
         return good
+
+    def _time_all_reduces(self, ar, numel: int, iters: int = 20) -> tuple:
+        """us per all-reduce of the gradient buffer: (direct kernel, process group), max over ranks."""
+        import time
+        tmp = torch.zeros(numel, device=self.device)
+        out = []
+        for fn in (lambda: ar.all_reduce(ar.flat[:numel], channel=2), lambda: td.all_reduce(tmp, op=td.ReduceOp.SUM)):
+            for _ in range(3):
+                fn()
+                torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(iters):                              # one at a time (the same for both paths): gloo's CUDA path,
+                fn()                                            # used for rehearsals, stalls on back-to-back collectives
+                torch.cuda.synchronize(self.device)
+            out.append((time.perf_counter() - t0) / iters * 1e6)
+        v = torch.tensor(out, dtype=torch.float64, device=self.device)
+        td.all_reduce(v, op=td.ReduceOp.MAX)
+        return float(v[0]), float(v[1])
 
     def check_health(self) -> None:
         """Raises if a poll of the direct all-reduce timed out since the last call (a peer did not arrive). Synchronises."""
