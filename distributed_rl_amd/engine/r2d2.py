@@ -21,6 +21,7 @@ Burn-in steps run the same kernels; gradients simply never flow past t = burn_in
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -31,11 +32,6 @@ from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
 from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
-
-
-def _os_environ_get(name: str):
-    import os
-    return os.environ.get(name)
 
 
 class SeqNetBuffers:
@@ -206,7 +202,7 @@ class R2D2Engine:
         self.dcol2 = torch.zeros(NB * 81, 512, **bf)
         self.d1 = torch.zeros(NB * 400, 32, **bf)
         self.wgrad_splits = wgrad_splits
-        import os as _os
+        _os = os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
@@ -240,7 +236,6 @@ class R2D2Engine:
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
-        import os
         self.persistent_lstm = H.lstm_seq_supported(B, Hd) and os.environ.get("DRL_PERSISTENT_LSTM", "1") != "0"
         self._graphs = None
         self.steps_done = 0
@@ -354,7 +349,7 @@ class R2D2Engine:
             # the persistent chain is faster than the torso backward it feeds: a smaller newest chunk starts the torso
             # earlier (2.49 / 2.44 / 2.43 / 2.45 ms for a cut at window step 64 / 56 / 48 / 40 of 80; more cuts: 2.59-2.61)
             starts = {0, (3 * L) // 5}
-        cuts_env = _os_environ_get("DRL_BWD_CUTS")                 # explicit chunk starts in window steps, e.g. "48,64"
+        cuts_env = os.environ.get("DRL_BWD_CUTS")                 # explicit chunk starts in window steps, e.g. "48,64"
         if cuts_env:
             starts = {0} | {int(c) for c in cuts_env.split(",") if c.strip() and 0 < int(c) < L}
         order = sorted(starts)
@@ -465,7 +460,6 @@ class R2D2Engine:
             self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        import os
         collective = self.dist is not None and self.dist.enabled
         if collective and self.dist.graph_collectives:
             self.dist.quiesce()        # the watchdog must have retired the warm-up steps' eager collectives (see Dist.quiesce)
