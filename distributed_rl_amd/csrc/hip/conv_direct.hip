@@ -86,9 +86,12 @@ struct Conv1Net {
     int M, per;
 };
 
-template <bool OFF>
+// PAIR: both networks convolve the SAME frames (R2D2 learner: online + target over one sequence batch) - n2 supplies only
+// weights / bias / output; every tile is loaded and converted once and multiplied with both weight sets.
+template <bool OFF, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, int nblk1) {
-    const bool second = (int)blockIdx.x >= nblk1;                      // block-uniform
+    static_assert(!PAIR || DRL_CONV1_F16, "the two-weight-set form exists for the f16 path only");
+    const bool second = !PAIR && (int)blockIdx.x >= nblk1;             // block-uniform
     const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
     const bf16_t* __restrict__ w = second ? n2.w : n1.w;
     const float* __restrict__ bias = second ? n2.bias : n1.bias;
@@ -119,6 +122,24 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
             for (int i = 0; i < 4; ++i) acc0[t][i] = -1024.0f * __shfl(csum[t], g * 4 + i, WAVE);   // accumulator row g*4+i
         }
     }
+    uint4 wf2[PAIR ? 2 : 1][PAIR ? 8 : 1];
+    float acc0b[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if constexpr (PAIR) {
+        float csum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                wf2[t][s] = bf16x8_to_f16(*reinterpret_cast<const bf16x8*>(n2.w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8),
+                                          csum[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            csum[t] += __shfl_xor(csum[t], 16, WAVE);
+            csum[t] += __shfl_xor(csum[t], 32, WAVE);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc0b[t][i] = -1024.0f * __shfl(csum[t], g * 4 + i, WAVE);
+        }
+    }
 #else
     bf16x8 wf[2][8];
 #pragma unroll
@@ -130,9 +151,12 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
     // MFMA row i of weight tile t is output channel (i/4)*8 + t*4 + i%4 (a free permutation of the weight rows): the
     // lane that ends up with accumulator rows g*4..g*4+3 of both tiles then owns the 8 CONSECUTIVE channels g*8..g*8+7
     // of its pixel: one 16-byte store per lane, 1 KB contiguous per wave and tile.
-    float4 b4[2];
+    float4 b4[2], b4b[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
+    for (int t = 0; t < 2; ++t) {
+        b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
+        b4b[t] = PAIR ? *reinterpret_cast<const float4*>(n2.bias + g * 8 + t * 4) : b4[t];
+    }
 
     // Byte offset of this lane's first fragment (patch row 0) in tile `tile` = frame base + pixel offset; rows past M
     // re-read row M-1. The frame base of a replay-store frame is itself a (dependent) global load: it is issued two
@@ -167,11 +191,16 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
 #if DRL_CONV1_F16
         f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
+        f32x4 accb[2] = {{acc0b[0][0], acc0b[0][1], acc0b[0][2], acc0b[0][3]}, {acc0b[1][0], acc0b[1][1], acc0b[1][2], acc0b[1][3]}};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const uint4 xf = u8x8_to_f16_biased(cur[s]);
             acc[0] = mfma16h(wf[0][s], xf, acc[0]);
             acc[1] = mfma16h(wf[1][s], xf, acc[1]);
+            if constexpr (PAIR) {
+                accb[0] = mfma16h(wf2[0][s], xf, accb[0]);
+                accb[1] = mfma16h(wf2[1][s], xf, accb[1]);
+            }
         }
 #else
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -192,6 +221,16 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
                 o[2 * t + 1] = pack_bf2(fmaxf(acc[t][2] * SC + b4[t].z, 0.f), fmaxf(acc[t][3] * SC + b4[t].w, 0.f));
             }
             *reinterpret_cast<uint4*>(out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+#if DRL_CONV1_F16
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[2 * t] = pack_bf2(fmaxf(accb[t][0] * SC + b4b[t].x, 0.f), fmaxf(accb[t][1] * SC + b4b[t].y, 0.f));
+                    o[2 * t + 1] = pack_bf2(fmaxf(accb[t][2] * SC + b4b[t].z, 0.f), fmaxf(accb[t][3] * SC + b4b[t].w, 0.f));
+                }
+                *reinterpret_cast<uint4*>(n2.out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+#endif
         }
         bnext = f2 + p2;
     };
@@ -364,4 +403,21 @@ DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int f
     const Conv1Net n2{frame_off2, (const bf16_t*)w2, bias2, (bf16_t*)out2, M2, per2};
     k_conv1_direct<true><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, g1);
     return (int)hipGetLastError();
+}
+
+// conv1 of TWO networks over the SAME frames (one frame-offset list): every tile is read and converted once.
+DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int frames, const void* w1, const float* bias1, void* out1,
+                               const void* w2, const float* bias2, void* out2, hipStream_t s) {
+#if DRL_CONV1_F16
+    if (frames <= 0 || !frame_off) return -1;
+    const int M = frames * 400;
+    int grid;
+    const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
+    const Conv1Net n1{frame_off, (const bf16_t*)w1, bias1, (bf16_t*)out1, M, per};
+    const Conv1Net n2{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
+    k_conv1_direct<true, true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n2, grid);
+    return (int)hipGetLastError();
+#else
+    return -1;
+#endif
 }

@@ -91,8 +91,12 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
     r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
     fo = frame_off[r0:r1]
     (wb1, wf1, b1, bs1), (wb2, wf2, b2, bs2) = net1, net2
-    H.conv_fwd_dual(1, frames, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], None, n, wb2.view("conv1.w"),
-                    wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
+    if os.environ.get("DRL_CONV1_PAIR", "1") != "0":   # every frame read and converted once, two weight sets per tile
+        H.conv1_fwd_pair(frames, fo, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], wb2.view("conv1.w"),
+                         wf2.view("conv1.b"), b2.act1[r0:r1])
+    else:
+        H.conv_fwd_dual(1, frames, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], None, n, wb2.view("conv1.w"),
+                        wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
                         getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1])

@@ -292,6 +292,18 @@ def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, ou
         "conv_fwd_dual")
 
 
+def conv1_fwd_pair(x, frame_off, frames: int, w1, b1, out1, w2, b2, out2) -> None:
+    """conv1 (+bias+ReLU) of TWO networks over the SAME frames of the store ``x`` (addressed through ``frame_off``): every
+    input tile is read and converted once and multiplied with both weight sets (R2D2 learner: online + target)."""
+    _chk(x, torch.uint8, "x"); _chk(frame_off, torch.int64, "frame_off")
+    for w, b, o in ((w1, b1, out1), (w2, b2, out2)):
+        _chk(w, torch.bfloat16, "w"); _chk(b, torch.float32, "bias"); _chk(o, torch.bfloat16, "out")
+        assert o.numel() == frames * 400 * 32
+    assert frame_off.numel() >= frames
+    _ck(native.hip().drl_conv1_fwd_pair(_p(x), _p(frame_off), frames, _p(w1), _p(b1), _p(out1), _p(w2), _p(b2), _p(out2), _s()),
+        "conv1_fwd_pair")
+
+
 def gemm_nt_dual(a1, w1, b1, c1, a2, w2, b2, c2, N: int, K: int, flags: int = 0) -> None:
     """c_i = epi(a_i[M_i,K] . w_i[N,K]^T + b_i) for two (a, w, b, c) sets in one launch (64x64 LDS-DMA tiles)."""
     for a, w, c in ((a1, w1, c1), (a2, w2, c2)):

@@ -801,3 +801,20 @@ def test_lstm_bptt_persistent_matches_step_launches(hip, M):
     torch.cuda.synchronize()
     assert int(err.item()) == 0
     torch.testing.assert_close(dG.float().cpu(), dG_ref.float().cpu(), rtol=3e-2, atol=2e-4)
+
+
+@pytest.mark.parametrize("frames", [5, 130])
+def test_conv1_fwd_pair_matches_single_network_launches(hip, frames):
+    """Two weight sets per tile over the same frames: bit-identical to two single-network launches."""
+    H = hip
+    store = torch.randint(0, 256, (frames + 7, 84, 84, 4), dtype=torch.uint8).to(DEV)
+    off = (torch.randperm(frames + 7)[:frames] * 28224).to(DEV)
+    outs = []
+    nets = [_conv_setup(1, 1, 40 + i)[2:4] for i in range(2)]
+    for w, b in nets:
+        o = torch.zeros(frames, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+        H.conv_fwd(1, store, w.to(DEV), b.to(DEV), o, frames, frame_off=off)
+        outs.append(o)
+    p1, p2 = torch.zeros_like(outs[0]), torch.zeros_like(outs[0])
+    H.conv1_fwd_pair(store, off, frames, nets[0][0].to(DEV), nets[0][1].to(DEV), p1, nets[1][0].to(DEV), nets[1][1].to(DEV), p2)
+    assert torch.equal(p1, outs[0]) and torch.equal(p2, outs[1])
