@@ -86,12 +86,17 @@ struct Conv1Net {
     int M, per;
 };
 
-// PAIR: both networks convolve the SAME frames (R2D2 learner: online + target over one sequence batch) - n2 supplies only
-// weights / bias / output; every tile is loaded and converted once and multiplied with both weight sets.
-template <bool OFF, bool PAIR = false>
-__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, int nblk1) {
+// PAIR: the blocks of the SECOND range [nblk1, gridDim.x) also multiply every tile with a second weight set, n3 (weights /
+// bias / output only; the frames are those of n2): the tile is loaded and converted once for both networks. R2D2 learner:
+// online + target over one sequence batch (nblk1 = 0); Ape-X learner: online on s in the first range, online AND target
+// on s' in the second.
+// PAIR = 1: every block is a pair block (primary network n1, second weight set n3; decided at compile time);
+// PAIR = 2: the blocks of the second range are.
+template <bool OFF, int PAIR = 0>
+__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, Conv1Net n3, int nblk1) {
     static_assert(!PAIR || DRL_CONV1_F16, "the two-weight-set form exists for the f16 path only");
-    const bool second = !PAIR && (int)blockIdx.x >= nblk1;             // block-uniform
+    const bool second = PAIR != 1 && (int)blockIdx.x >= nblk1;         // block-uniform
+    const bool pair_blk = PAIR == 1 || (PAIR == 2 && second);
     const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
     const bf16_t* __restrict__ w = second ? n2.w : n1.w;
     const float* __restrict__ bias = second ? n2.bias : n1.bias;
@@ -124,13 +129,13 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
     }
     uint4 wf2[PAIR ? 2 : 1][PAIR ? 8 : 1];
     float acc0b[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if constexpr (PAIR) {
+    if (pair_blk) {
         float csum[2] = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < (PAIR ? 2 : 1); ++t)
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                wf2[t][s] = bf16x8_to_f16(*reinterpret_cast<const bf16x8*>(n2.w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8),
+            for (int s = 0; s < (PAIR ? 8 : 1); ++s)
+                wf2[t][s] = bf16x8_to_f16(*reinterpret_cast<const bf16x8*>(n3.w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8),
                                           csum[t]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
-        b4b[t] = PAIR ? *reinterpret_cast<const float4*>(n2.bias + g * 8 + t * 4) : b4[t];
+        b4b[t] = pair_blk ? *reinterpret_cast<const float4*>(n3.bias + g * 8 + t * 4) : b4[t];
     }
 
     // Byte offset of this lane's first fragment (patch row 0) in tile `tile` = frame base + pixel offset; rows past M
@@ -198,8 +203,10 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
             acc[0] = mfma16h(wf[0][s], xf, acc[0]);
             acc[1] = mfma16h(wf[1][s], xf, acc[1]);
             if constexpr (PAIR) {
-                accb[0] = mfma16h(wf2[0][s], xf, accb[0]);
-                accb[1] = mfma16h(wf2[1][s], xf, accb[1]);
+                if (pair_blk) {
+                    accb[0] = mfma16h(wf2[0][s], xf, accb[0]);
+                    accb[1] = mfma16h(wf2[1][s], xf, accb[1]);
+                }
             }
         }
 #else
@@ -222,13 +229,13 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
             }
             *reinterpret_cast<uint4*>(out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 #if DRL_CONV1_F16
-            if constexpr (PAIR) {
+            if (pair_blk) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     o[2 * t] = pack_bf2(fmaxf(accb[t][0] * SC + b4b[t].x, 0.f), fmaxf(accb[t][1] * SC + b4b[t].y, 0.f));
                     o[2 * t + 1] = pack_bf2(fmaxf(accb[t][2] * SC + b4b[t].z, 0.f), fmaxf(accb[t][3] * SC + b4b[t].w, 0.f));
                 }
-                *reinterpret_cast<uint4*>(n2.out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(n3.out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
             }
 #endif
         }
@@ -364,8 +371,8 @@ DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const f
         int grid;
         const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
         const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
-        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
-        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, grid);
+        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
+        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
     } else if (layer == 2) {
         if ((long long)frames * 20 * 20 * 32 >= (1LL << 32)) return -8;
         const int M = frames * 81;
@@ -401,7 +408,7 @@ DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int f
     const int per1 = plan((M1 + 15) / 16, s1 > 0 ? s1 : 1, 4, &g1), per2 = plan((M2 + 15) / 16, s2 > 0 ? s2 : 1, 4, &g2);
     const Conv1Net n1{frame_off1, (const bf16_t*)w1, bias1, (bf16_t*)out1, M1, per1};
     const Conv1Net n2{frame_off2, (const bf16_t*)w2, bias2, (bf16_t*)out2, M2, per2};
-    k_conv1_direct<true><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, g1);
+    k_conv1_direct<true><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, n2, g1);
     return (int)hipGetLastError();
 }
 
@@ -414,8 +421,32 @@ DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int fr
     int grid;
     const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
     const Conv1Net n1{frame_off, (const bf16_t*)w1, bias1, (bf16_t*)out1, M, per};
-    const Conv1Net n2{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
-    k_conv1_direct<true, true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n2, grid);
+    const Conv1Net n3{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
+    k_conv1_direct<true, 1><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n3, grid);
+    return (int)hipGetLastError();
+#else
+    return -1;
+#endif
+}
+
+// Ape-X learner: network 1 on frames1 (through frame_off1 -> out1a) AND on frames2 (frame_off2 -> out1b), network 2 on
+// frames2 only (-> out2): the blocks of the second range multiply every tile of frames2 with both weight sets.
+DRL_API int drl_conv1_fwd_apex(const void* x, const long long* frame_off1, int frames1, const long long* frame_off2, int frames2,
+                               const void* w1, const float* bias1, void* out1a, void* out1b, const void* w2, const float* bias2,
+                               void* out2, hipStream_t s) {
+#if DRL_CONV1_F16
+    if (frames1 <= 0 || frames2 <= 0 || !frame_off1 || !frame_off2) return -1;
+    int g1, g2;
+    const int slots = 256 * DRL_CONV1_WAVES_PER_CU;
+    const int M1 = frames1 * 400, M2 = frames2 * 400;
+    // a pair tile costs about 1.6 single tiles (two MFMA sets, one load + conversion): split the wave slots accordingly
+    const long long wgt1 = 10LL * M1, wgt2 = 16LL * M2;
+    const int s1 = (int)((long long)slots * wgt1 / (wgt1 + wgt2)), s2 = slots - s1;
+    const int per1 = plan((M1 + 15) / 16, s1 > 0 ? s1 : 1, 4, &g1), per2 = plan((M2 + 15) / 16, s2 > 0 ? s2 : 1, 4, &g2);
+    const Conv1Net n1{frame_off1, (const bf16_t*)w1, bias1, (bf16_t*)out1a, M1, per1};
+    const Conv1Net n2{frame_off2, (const bf16_t*)w1, bias1, (bf16_t*)out1b, M2, per2};
+    const Conv1Net n3{frame_off2, (const bf16_t*)w2, bias2, (bf16_t*)out2, M2, per2};
+    k_conv1_direct<true, 2><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, n3, g1);
     return (int)hipGetLastError();
 #else
     return -1;

@@ -56,11 +56,18 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 
 def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
-                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers) -> None:
+                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers,
+                       shared_tail: bool = False) -> None:
     """Forward of TWO networks (online on n1 frames, target on n2 frames), 5 launches in total: each layer of both networks
     is one launch, so the learner's step needs no second stream (no fork / join) for the target network."""
-    H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
-                    wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
+    if shared_tail and n1 == 2 * n2:
+        # the second network's frames ARE the second half of the first network's (online on [s ; s'], target on s'):
+        # those tiles are read and converted once and multiplied with both weight sets
+        H.conv1_fwd_apex(x_u8, off1[:n2], n2, off2, n2, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[:n2], b1.act1[n2:],
+                         wb2.view("conv1.w"), wf2.view("conv1.b"), b2.act1)
+    else:
+        H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
+                        wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
                         getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst))
@@ -118,6 +125,9 @@ class ApexEngine:
         if self.presample:
             replay._next_buffers()                                        # allocate now, never inside a graph capture
         self.dual_fwd = _os.environ.get("DRL_DUAL_FWD", "1") != "0"       # online + target forward as one launch per layer
+        # s' read + converted once for the online and the target conv1 (two weight sets per tile in part of the launch):
+        # measured SLOWER here (0.2465 vs 0.2400 ms: the heavier pair blocks set the launch's registers and its tail), off
+        self.conv1_pair = _os.environ.get("DRL_APEX_CONV1_PAIR", "0") != "0"
         self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
@@ -167,7 +177,8 @@ class ApexEngine:
         if not (self.presample and self._primed):
             r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
         if self.dual_fwd:
-            torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg)
+            torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
+                               shared_tail=self.conv1_pair)
         else:
             with self._fork(0):                                    # target net on s' || online net on [s ; s']
                 torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)

@@ -36,6 +36,7 @@ SIGS = {
     "drl_gemm_nt_dual": [P, I, P, P, P, P, I, P, P, P, I, I, I, P],
     "drl_conv1_fwd_dual": [P, P, I, P, P, P, P, I, P, P, P, P],
     "drl_conv1_fwd_pair": [P, P, I, P, P, P, P, P, P, P],
+    "drl_conv1_fwd_apex": [P, P, I, P, I, P, P, P, P, P, P, P, P],
     # conv_direct.hip
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],

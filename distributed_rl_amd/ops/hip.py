@@ -304,6 +304,19 @@ def conv1_fwd_pair(x, frame_off, frames: int, w1, b1, out1, w2, b2, out2) -> Non
         "conv1_fwd_pair")
 
 
+def conv1_fwd_apex(x, off1, f1: int, off2, f2: int, w1, b1, out1a, out1b, w2, b2, out2) -> None:
+    """conv1 of the Ape-X learner's forward in one launch: network 1 on f1 frames (off1 -> out1a) and on f2 frames (off2 ->
+    out1b), network 2 on the same f2 frames (-> out2) - those are read and converted once for both networks."""
+    _chk(x, torch.uint8, "x"); _chk(off1, torch.int64, "off1"); _chk(off2, torch.int64, "off2")
+    for w, b in ((w1, b1), (w2, b2)):
+        _chk(w, torch.bfloat16, "w"); _chk(b, torch.float32, "bias")
+    for o, f in ((out1a, f1), (out1b, f2), (out2, f2)):
+        _chk(o, torch.bfloat16, "out")
+        assert o.numel() == f * 400 * 32 and o.is_contiguous()
+    _ck(native.hip().drl_conv1_fwd_apex(_p(x), _p(off1), f1, _p(off2), f2, _p(w1), _p(b1), _p(out1a), _p(out1b), _p(w2), _p(b2),
+                                        _p(out2), _s()), "conv1_fwd_apex")
+
+
 def gemm_nt_dual(a1, w1, b1, c1, a2, w2, b2, c2, N: int, K: int, flags: int = 0) -> None:
     """c_i = epi(a_i[M_i,K] . w_i[N,K]^T + b_i) for two (a, w, b, c) sets in one launch (64x64 LDS-DMA tiles)."""
     for a, w, c in ((a1, w1, c1), (a2, w2, c2)):

@@ -818,3 +818,19 @@ def test_conv1_fwd_pair_matches_single_network_launches(hip, frames):
     p1, p2 = torch.zeros_like(outs[0]), torch.zeros_like(outs[0])
     H.conv1_fwd_pair(store, off, frames, nets[0][0].to(DEV), nets[0][1].to(DEV), p1, nets[1][0].to(DEV), nets[1][1].to(DEV), p2)
     assert torch.equal(p1, outs[0]) and torch.equal(p2, outs[1])
+
+
+def test_conv1_fwd_apex_layout_matches_single_network_launches(hip):
+    """Network 1 on [s ; s'], network 2 on s' with the s' tiles shared: bit-identical to single-network launches."""
+    H = hip
+    B = 37
+    store = torch.randint(0, 256, (2 * B + 3, 84, 84, 4), dtype=torch.uint8).to(DEV)
+    off = (torch.randperm(2 * B + 3)[:2 * B] * 28224).to(DEV)
+    (w1, b1), (w2, b2) = [tuple(t.to(DEV) for t in _conv_setup(1, 1, 60 + i)[2:4]) for i in range(2)]
+    ref1 = torch.zeros(2 * B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    ref2 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    H.conv_fwd(1, store, w1, b1, ref1, 2 * B, frame_off=off)
+    H.conv_fwd(1, store, w2, b2, ref2, B, frame_off=off[B:])
+    o1, o2 = torch.zeros_like(ref1), torch.zeros_like(ref2)
+    H.conv1_fwd_apex(store, off[:B], B, off[B:], B, w1, b1, o1[:B], o1[B:], w2, b2, o2)
+    assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
