@@ -27,6 +27,7 @@ from ..models import DuelingDQN
 from ..models.packing import ParamPack, apex_layout
 from ..ops import hip as H
 from ..replay.device_per import DevicePER
+from .shard import ShardedIS
 from .streams import ForkJoin, capture_graph
 
 
@@ -77,7 +78,7 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
                     b2.h, wb2.view("adv2.w"), wf2.view("adv2.b"), wb2.view("val2.w"), wf2.view("val2.b"), b2.q)
 
 
-class ApexEngine:
+class ApexEngine(ShardedIS):
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
                  overlap: bool = True):
@@ -116,7 +117,7 @@ class ApexEngine:
         self.wgrad_splits = wgrad_splits
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
-        self.n_scale = 1.0                               # N_global / (world * N_local): see refresh_shard_scalars
+        self._init_shard(replay, dist, dev)              # self.n_is: device scalar N_global / world (engine/shard.py)
         import os as _os
         self.overlap_comm = _os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
         self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
@@ -142,21 +143,6 @@ class ApexEngine:
         self.T.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
 
-    def refresh_shard_scalars(self) -> float:
-        """Sharded PER: rank r draws its batch from its own shard, so item i is drawn with probability
-        p_i / (world * Σp_local) and its single-tree-equivalent IS weight is (N_global * p_i / (world * Σp_local))^-β.
-        The TD kernel computes (n_scale * N_local * p_i / Σp_local)^-β, hence n_scale = N_global / (world * N_local)
-        (= 1 for equally filled shards). One tiny all-reduce, called at capture time: the value is baked into the graph.
-        Every rank must call it at the same point (it is a collective); shards fed by equally many actors fill at the
-        same rate, so the ratio stays ~1 after that."""
-        if self.dist is None or not self.dist.enabled:
-            self.n_scale = 1.0
-            return 1.0
-        n_local = int(self.replay.n_items.item())
-        _, n_global = self.dist.shard_scalars(0.0, n_local)
-        self.n_scale = float(n_global) / float(max(1, self.world * n_local))
-        return self.n_scale
-
     def _fork(self, i: int):
         return self.fj.fork(i)
 
@@ -175,7 +161,7 @@ class ApexEngine:
         # step_begin fused; G was zeroed by the optimizer. fused_bwd: the sampler also accumulates the max IS weight.
         # presample: from the second step on the batch was already drawn by the previous step's optimizer launch.
         if not (self.presample and self._primed):
-            r.sample(self.st, begin=True, is_n_scale=self.n_scale if self.fused_bwd else 0.0)
+            r.sample(self.st, begin=True, is_n_scale=1.0 if self.fused_bwd else 0.0, n_is=self.n_is)
         if self.dual_fwd:
             torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
                                shared_tail=self.conv1_pair)
@@ -187,7 +173,7 @@ class ApexEngine:
         G, Pb, on = self.G, self.Pb, self.on
         if not self.fused_bwd:
             H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                      cfg.prio_eps, self.dq, self.new_prio, n_scale=self.n_scale)
+                      cfg.prio_eps, self.dq, self.new_prio)
         h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
         hb = (self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
@@ -195,8 +181,7 @@ class ApexEngine:
         if self.fused_bwd:
             # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)
             H.apex_td_dh(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                         cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh,
-                         n_scale=self.n_scale)
+                         cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh)
             # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
             H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
                      head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))
@@ -226,7 +211,7 @@ class ApexEngine:
             # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
             # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
             H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
-                       splits=4 * sp, sample=r.sample_extra(self.st, self.n_scale) if self.presample else None)
+                       splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None)
             self._join()
             return
         with self._fork(1):                                        # conv3 dW, db || conv3 dX
@@ -339,6 +324,7 @@ class ApexEngine:
         self.steps_done += 2
 
     def step(self) -> None:
+        self._maybe_refresh_shard()                      # outside the graph: the replay below reads the device scalar
         if self.use_graph:
             if self._graphs is None:
                 self.capture()

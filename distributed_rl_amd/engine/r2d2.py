@@ -30,6 +30,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
+from .shard import ShardedIS
 from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
 
@@ -157,7 +158,7 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
     seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent, bsum=bsum)
 
 
-class R2D2Engine:
+class R2D2Engine(ShardedIS):
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
                  done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks: int = 2):
@@ -181,6 +182,7 @@ class R2D2Engine:
         H.cast_bf16(self.P.flat, self.Pb.flat)
         self.sync_target()
         self.st = H.new_step_state(dev, cfg.beta0, cfg.beta_decay)
+        self._init_shard(replay, dist, dev)               # self.n_is: device scalar N_global / world (engine/shard.py)
         self.partial = torch.zeros(1024, device=dev)
         self.n_partial = H.n_partials(self.P.flat.numel())
         self.on = SeqNetBuffers(T, B, Hd, n_action, dev, True)
@@ -256,7 +258,7 @@ class R2D2Engine:
 
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
-        r.sample(self.st, begin=True)                               # step_begin fused; G was zeroed by the optimizer
+        r.sample(self.st, begin=True, n_is=self.n_is)               # step_begin fused; G was zeroed by the optimizer
         fj = self.fj
         # forward. The two nets are STAGGERED, not run side by side: the torso is throughput-bound, the recurrence is
         # latency-bound (32 workgroups), so the target torso runs under the online recurrence and the two recurrences
@@ -458,6 +460,7 @@ class R2D2Engine:
         self._optimize()
 
     def capture(self) -> None:
+        self.refresh_shard_scalars()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -484,6 +487,7 @@ class R2D2Engine:
         self.steps_done += 1
 
     def step(self) -> None:
+        self._maybe_refresh_shard()                      # outside the graph: the replay below reads the device scalar
         if self.use_graph:
             if self._graphs is None:
                 self.capture()

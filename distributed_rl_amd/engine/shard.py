@@ -1,0 +1,47 @@
+"""Sharded prioritized replay: the scalars that make per-shard sampling equivalent to ONE tree (SURVEY §2.5 M8, §5.8;
+the reference has a single replay, ape_x/learner.py:64-68).
+
+Rank r draws its batch from its own shard, so item i is drawn with probability ``p_i / (W * Σp_r)`` (every rank
+contributes 1/W of the global batch) and its importance weight is ``(N_global * p_i / (W * Σp_r))^-β``. The kernels compute
+``(n * p_i / Σp_local)^-β`` with ``n`` read from an int64 DEVICE scalar at sampling time, so all a sharded run has to do is
+keep ``n = N_global / W`` in that scalar: ``ShardedIS.n_is``. It is refreshed OUTSIDE the captured step graph every
+``DRL_SHARD_REFRESH`` steps (one 8-byte all-reduce, no host synchronisation), so shards that fill at different rates
+stay correct without re-capturing anything; with one rank it simply aliases the replay's own item counter.
+
+The max-weight normalisation of the batch stays per rank (its own batch's maximum): the global maximum would need a
+collective between sampling and the TD kernel; it only scales a rank's loss by a factor close to 1 (documented
+deviation, README).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+
+class ShardedIS:
+    def _init_shard(self, replay, dist, device) -> None:
+        self._shard_on = dist is not None and dist.enabled and dist.world_size > 1
+        self.shard_refresh = max(1, int(os.environ.get("DRL_SHARD_REFRESH", "64")))
+        if self._shard_on:
+            self.n_is = torch.zeros(1, dtype=torch.int64, device=device)
+            self._n_tmp = torch.zeros(1, dtype=torch.int64, device=device)
+        else:
+            self.n_is = replay.n_items
+        self._shard_fresh = False
+
+    def _maybe_refresh_shard(self) -> None:
+        """Top of every ``step()``: the first step and every ``shard_refresh``-th one re-read the global item count. All
+        ranks step in lockstep, so they take this collective at the same points."""
+        if self._shard_on and (not self._shard_fresh or self.steps_done % self.shard_refresh == 0):
+            self.refresh_shard_scalars()
+            self._shard_fresh = True
+
+    def refresh_shard_scalars(self) -> None:
+        """Collective (every rank calls it at the same step): n_is <- round(sum_r N_r / W). Device-side, asynchronous."""
+        if self._shard_on:
+            self.dist.mean_count(self.replay.n_items, self.n_is, self._n_tmp)
+
+    def shard_n_is(self) -> int:
+        """Host copy of the item count the IS weights use (tests / stats; synchronises)."""
+        return int(self.n_is.item())

@@ -59,6 +59,17 @@ def is_weights(prios: torch.Tensor, total_prio, n_items, beta: float,
     return (w / m).float()
 
 
+def sharded_is_weights(prios: torch.Tensor, shard_total_prio, n_global, world: int, beta: float,
+                       max_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """IS weights of a batch drawn from ONE shard of a sharded replay: every rank contributes 1/world of
+    the global batch from its own tree, so item i is drawn with probability p_i / (world * Σp_shard) and
+    w = (N_global * p_i / (world * Σp_shard))^-β / max w. With equal Σp per shard this IS the single-tree weight of
+    ``is_weights`` (learner.py:67-68); with unequal shards it is the weight that keeps the estimator unbiased for the
+    distribution actually sampled. The engines realise it by feeding N_global / world to the kernels as the item count
+    (engine/shard.py)."""
+    return is_weights(prios, shard_total_prio, float(n_global) / float(world), beta, max_weight)
+
+
 # --------------------------------------------------------------------------------------------
 # Ape-X n-step double-DQN TD / Huber / priority   (models.py:41-48, learner.py:72)
 # --------------------------------------------------------------------------------------------

@@ -57,6 +57,9 @@ class Dist:
         # DRL_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
         self.enabled = self.world_size > 1 or os.environ.get("DRL_FORCE_DIST") == "1"
         self.xgmi = None                                       # direct xGMI all-reduce, see grad_buffer()
+        self._xgmi_busy, self._xgmi_tried = False, False
+        self.xgmi_reserve_numel = 0                            # make the direct all-reduce's buffer at least this large
+        self.fallbacks = []                                    # every degraded path taken, for the bench's JSON line
         self.all_reduce_us = None                              # {"direct_xgmi": us, "process_group": us} measured by grad_buffer()
         if self.enabled and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -74,14 +77,26 @@ class Dist:
         path is available AND has just reproduced RCCL's result on this very set of GPUs; otherwise ``None`` (the
         engine allocates an ordinary tensor and the collectives go through RCCL).
 
+        The buffer is created once per process (``xgmi_reserve_numel`` makes it large enough for every engine the process
+        will build); one engine owns it at a time and hands it back with :meth:`release_grad_buffer`.
+
         ``DRL_XGMI_AR`` = 0: never; 1: required (failures raise); unset / "auto": try, verify, fall back. Collective call:
         every rank must make it at the same point."""
         mode = os.environ.get("DRL_XGMI_AR", "auto")
+        if self.xgmi is not None:                               # reuse by the next engine of this process
+            if self._xgmi_busy or numel > self.xgmi.cap:
+                self.fallbacks.append("xgmi->process_group: buffer busy or too small for %d elements" % numel)
+                return None
+            self._xgmi_busy = True
+            self.xgmi.flat.zero_()
+            return self.xgmi.flat[:numel]
         usable = (self.enabled and mode != "0" and self.device.type == "cuda" and 2 <= self.world_size <= 8
-                  and self.xgmi is None)
+                  and not self._xgmi_tried)
         if not usable:
             return None
-        ar, why = None, ""
+        self._xgmi_tried = True
+        ar, why, ok = None, "", False
+        cap = max(int(numel), int(self.xgmi_reserve_numel))
         try:
             import socket
             hosts = [None] * self.world_size
@@ -89,23 +104,26 @@ class Dist:
             if len(set(hosts)) != 1:
                 raise RuntimeError("ranks on different hosts")
             from .xgmi import XgmiAllReduce
-            ar = XgmiAllReduce(numel, self.device, self.rank, self.world_size,
+            ar = XgmiAllReduce(cap, self.device, self.rank, self.world_size,
                                n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")))
-            ok = self._verify_xgmi(ar, numel)
-            # both paths are correct here: keep the direct kernel unless the process group's all-reduce is clearly faster on
-            # THIS node (every rank times both - collective calls - and the slowest rank's numbers decide)
-            t_x, t_pg = self._time_all_reduces(ar, numel)
-            self.all_reduce_us = {"direct_xgmi": round(t_x, 1), "process_group": round(t_pg, 1)}
-            if ok and mode != "1" and t_x > 1.25 * t_pg:
-                ok, why = False, "slower than the process group here: %.0f vs %.0f us" % (t_x, t_pg)
+            ok = self._verify_xgmi(ar, numel)                   # keeps the 1 s poll bound: see _agree below
         except Exception as e:                                  # noqa: BLE001 - any failure means "use RCCL"
             ok, why = False, repr(e)
-        try:                                                    # same verdict on every rank
-            v = torch.tensor([1.0 if ok else 0.0], device=self.device)
-            td.all_reduce(v, op=td.ReduceOp.MIN)
-            ok = float(v.item()) > 0.5
-        except Exception as e:                                  # noqa: BLE001
-            ok, why = False, why or repr(e)
+        # the verdict of the verification is agreed on BEFORE anything else is launched on the direct path: on a broken
+        # IPC / xGMI path every further launch would burn its poll bound in three timed-out barriers
+        ok = self._agree(ok)
+        if ok:
+            try:
+                ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
+                # both paths are correct here: keep the direct kernel unless the process group's all-reduce is clearly
+                # faster on THIS node (every rank times both - collective calls - and the slowest rank's numbers decide)
+                t_x, t_pg = self._time_all_reduces(ar, numel)
+                self.all_reduce_us = {"direct_xgmi": round(t_x, 1), "process_group": round(t_pg, 1)}
+                if mode != "1" and t_x > 1.25 * t_pg:
+                    ok, why = False, "slower than the process group here: %.0f vs %.0f us" % (t_x, t_pg)
+            except Exception as e:                              # noqa: BLE001
+                ok, why = False, repr(e)
+            ok = self._agree(ok)
         if not ok:
             if ar is not None:
                 try:
@@ -114,19 +132,35 @@ class Dist:
                     pass
             if mode == "1":
                 raise RuntimeError("DRL_XGMI_AR=1 but the direct xGMI all-reduce is not usable: %s" % (why or "mismatch"))
+            self.fallbacks.append("xgmi->process_group: %s" % (why or "verification failed on some rank"))
             if self.rank == 0:
                 import sys
                 print("[dist] direct xGMI all-reduce not used (%s); gradients go through RCCL" % (why or "verification failed"),
                       file=sys.stderr, flush=True)
             return None
         self.xgmi = ar
+        self._xgmi_busy = True
         self._xgmi_stream = torch.cuda.Stream(self.device)
         ar.flat.zero_()
         return ar.flat[:numel]
 
+    def release_grad_buffer(self) -> None:
+        """The engine that owned the direct all-reduce's buffer is gone: the next ``grad_buffer`` call may have it."""
+        self._xgmi_busy = False
+
+    def _agree(self, ok: bool) -> bool:
+        """Same verdict on every rank (MIN); a rank that cannot even take the collective votes no."""
+        try:
+            v = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            td.all_reduce(v, op=td.ReduceOp.MIN)
+            return float(v.item()) > 0.5
+        except Exception:                                       # noqa: BLE001
+            return False
+
     def _verify_xgmi(self, ar, numel: int) -> bool:
-        """The kernel against RCCL on rank-dependent random data: whole buffer, an engine-like split on two channels, a
-        captured + replayed launch. Any mismatch or timed-out poll rejects the path."""
+        """The kernel against RCCL on rank-dependent random data: whole buffer, an engine-like split on two channels. Any
+        mismatch, launch error or timed-out poll rejects the path. The loop contains collectives of the process group:
+        every rank takes all of them, whatever happens to its own kernel launches (a local failure is only recorded)."""
         g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
         cut = (numel // 41) // 64 * 64
         ar.set_timeout(1.0)                                     # a broken path must fail fast, not look like a hang
@@ -137,16 +171,17 @@ class Dist:
             want = ar.flat.clone()
             td.all_reduce(want, op=td.ReduceOp.SUM)
             torch.cuda.synchronize(self.device)
-            if k == 0:
-                ar.all_reduce(ar.flat[:numel], channel=0)
-            else:
-                ar.all_reduce(ar.flat[cut:numel], channel=0)
-                ar.all_reduce(ar.flat[:cut], channel=1)
-            torch.cuda.synchronize(self.device)
-            # no early return: the loop contains collectives of the process group, every rank takes all of them
-            good = good and ar.error() == 0 and bool(torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4))
-        ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
-        return good
+            try:
+                if k == 0:
+                    ar.all_reduce(ar.flat[:numel], channel=0)
+                else:
+                    ar.all_reduce(ar.flat[cut:numel], channel=0)
+                    ar.all_reduce(ar.flat[:cut], channel=1)
+                torch.cuda.synchronize(self.device)
+                good = good and ar.error() == 0 and bool(torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4))
+            except Exception:                                   # noqa: BLE001
+                good = False
+        return good                                             # the caller restores the production poll bound
 
     def _time_all_reduces(self, ar, numel: int, iters: int = 20) -> tuple:
         """us per all-reduce of the gradient buffer: (direct kernel, process group), max over ranks."""
@@ -214,15 +249,21 @@ class Dist:
     # ---- collectives inside hipGraphs -------------------------------------------------------------------
     @property
     def graph_collectives(self) -> bool:
-        """May the engines capture RCCL collectives INTO their step graph (no host work between graph pieces: 0.32 vs
-        0.38 ms per Ape-X step at one rank)? ``DRL_GRAPH_COLLECTIVES`` = 0 / 1 decides when set; otherwise a trial
-        decides once: a small all-reduce is captured, replayed twice and checked on every rank, and the ranks agree
-        on the verdict (MIN) so that all of them build the same kind of step."""
+        """May the engines put their collectives INTO the step graph (no host work between graph pieces)?
+
+        * direct xGMI all-reduce active: yes - it is an ordinary kernel launch (``DRL_GRAPH_COLLECTIVES=0`` still says no);
+        * RCCL: only on request (``DRL_GRAPH_COLLECTIVES=1``, checked by a captured trial all-reduce that every rank must
+          pass). Capturing a library collective races with the process group's watchdog thread (docs/DESIGN.md section 5:
+          an eager collective retired less than a polling period before the capture aborts the process), and the only
+          guard is a sleep; the default for RCCL is therefore the split schedule - graphs with the collectives issued
+          between them - which has no such window."""
         env = os.environ.get("DRL_GRAPH_COLLECTIVES")
         if self.xgmi is not None and env != "0":
-            return True                                        # the direct all-reduce is an ordinary kernel launch
-        if env in ("0", "1"):
-            return env == "1"
+            return True
+        if env != "1":
+            if self.enabled and "graph->split" not in " ".join(self.fallbacks):
+                self.fallbacks.append("one graph->split graphs: RCCL collectives are issued between graph pieces")
+            return False
         if getattr(self, "_graph_ok", None) is None:
             self._graph_ok = self._trial_graph_collective()
         return self._graph_ok
@@ -283,6 +324,26 @@ class Dist:
         t = torch.tensor([total_prio, float(n_items)], dtype=torch.float64, device=self.device)
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return float(t[0]), int(t[1])
+
+    def mean_count(self, n_local: torch.Tensor, out: torch.Tensor, tmp: torch.Tensor) -> None:
+        """out <- round(sum over ranks of n_local / world) for int64 device scalars (sharded PER, engine/shard.py).
+        ``out`` keeps its address: captured graphs read it. RCCL: stream-ordered, no host synchronisation. gloo on GPU
+        tensors (rehearsals with ranks sharing a device) blocks the host inside the collective while step graphs with
+        spinning inter-process kernels are still queued - observed to deadlock the shared device's queues - so that
+        path drains the stream first and reduces on the host."""
+        if not self.enabled:
+            out.copy_(n_local)
+            return
+        if self.backend != "nccl" and n_local.is_cuda:
+            torch.cuda.synchronize(self.device)
+            t = n_local.cpu()
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            out.copy_((t + self.world_size // 2) // self.world_size)
+            return
+        tmp.copy_(n_local)
+        td.all_reduce(tmp, op=td.ReduceOp.SUM)
+        tmp.add_(self.world_size // 2)
+        out.copy_(torch.div(tmp, self.world_size, rounding_mode="floor"))
 
     def max_scalar(self, x: float) -> float:
         if not self.enabled:

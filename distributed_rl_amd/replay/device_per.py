@@ -56,6 +56,21 @@ class DevicePER:
     def __len__(self) -> int:
         return self.count
 
+    def with_batch(self, batch_size: int) -> "DevicePER":
+        """A second sampler over the SAME store (frames, tree, generations are shared, the sample buffers are its own):
+        e.g. the strong-scaling measurement of bench.py draws 512 / world per rank from the shard the weak-scaling run
+        filled. Ingest through either object, not both."""
+        import copy
+        o = copy.copy(self)
+        B, dev = int(batch_size), self.device
+        o.batch_size = B
+        o.idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        o.prio = torch.zeros(B, device=dev)
+        o.gen_s = torch.zeros(B, dtype=torch.int32, device=dev)
+        o.frame_off = torch.zeros(2 * B, dtype=torch.int64, device=dev)
+        o._nxt = None
+        return o
+
     def total_prios(self) -> float:
         top = self.lay.offsets[-1]
         return float(self.tree[top:top + 64].sum())
@@ -113,12 +128,15 @@ class DevicePER:
             done += k
 
     # ---- sample / update (graph-capturable) -----------------------------------------------------
-    def sample(self, st: torch.Tensor, begin: bool = False, is_n_scale: float = 0.0) -> None:
+    def sample(self, st: torch.Tensor, begin: bool = False, is_n_scale: float = 0.0,
+               n_is: Optional[torch.Tensor] = None) -> None:
         """Draw ``batch_size`` slots ∝ priority into ``self.idx / prio / gen_s / frame_off``. ``begin`` fuses
         step_begin (beta / n_items refresh, fresh Philox counter) into the sampling kernel; ``is_n_scale`` > 0 also
-        accumulates the batch's max IS weight there (see ops.hip.sumtree_sample)."""
+        accumulates the batch's max IS weight there (see ops.hip.sumtree_sample). ``n_is`` (int64 device scalar)
+        replaces the live item count in the IS weights: sharded PER passes N_global / world (engine.shard_n_is)."""
+        n = (n_is if n_is is not None else self.n_items) if begin else None
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
-                         self.frame_bytes, begin_n_items=self.n_items if begin else None, is_n_scale=is_n_scale)
+                         self.frame_bytes, begin_n_items=n, is_n_scale=is_n_scale)
 
     def _next_buffers(self):
         if getattr(self, "_nxt", None) is None:
@@ -126,13 +144,13 @@ class DevicePER:
                          torch.zeros_like(self.frame_off))
         return self._nxt
 
-    def sample_extra(self, st: torch.Tensor, is_n_scale: float):
+    def sample_extra(self, st: torch.Tensor, is_n_scale: float, n_is: Optional[torch.Tensor] = None):
         """``sample(st, begin=True, is_n_scale=...)`` as a record that draws into the NEXT-batch buffers: the learner engine
         hands it to the conv1 backward launch (ops.hip.conv_bwd(1, ..., sample=...)), which still reads the current
         frame offsets, and ``handover_extra`` to the optimizer launch."""
         idx, prio, gen_s, foff = self._next_buffers()
         return H.sample_extra(self.tree, self.lay, st, self.seed, idx, prio, self.gen, gen_s, foff, self.frame_bytes,
-                              self.n_items, is_n_scale)
+                              n_is if n_is is not None else self.n_items, is_n_scale)
 
     def handover_extra(self):
         """Copies next-batch buffers -> live sample buffers (ops.hip.rmsprop_step(copies=...))."""

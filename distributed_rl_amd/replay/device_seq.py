@@ -107,9 +107,10 @@ class DeviceSequenceReplay:
             done_n += k
 
     # ---- graph-capturable ------------------------------------------------------------------------------
-    def sample(self, st: torch.Tensor, begin: bool = False) -> None:
+    def sample(self, st: torch.Tensor, begin: bool = False, n_is: Optional[torch.Tensor] = None) -> None:
+        """``n_is``: item count used by the IS weights instead of this shard's own (sharded PER: N_global / world)."""
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s,
-                         begin_n_items=self.n_items if begin else None)
+                         begin_n_items=(n_is if n_is is not None else self.n_items) if begin else None)
         H.seq_offsets(self.idx, self.T, self.frame_bytes, self.frame_off)
 
     def update(self, new_prio: torch.Tensor, end_state=None) -> None:

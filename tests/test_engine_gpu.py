@@ -86,7 +86,7 @@ def test_apex_engine_step_matches_oracle():
     assert eng.stats()["step"] == 1
     if eng.presample:                 # the pre-drawn batch is what a start-of-step sampler would draw for step 1
         pre_idx, pre_prio = rep.idx.clone(), rep.prio.clone()
-        rep.sample(eng.st, begin=True, is_n_scale=eng.n_scale)
+        rep.sample(eng.st, begin=True, is_n_scale=1.0)
         torch.cuda.synchronize()
         assert torch.equal(pre_idx, rep.idx) and torch.equal(pre_prio, rep.prio)
 
@@ -178,8 +178,11 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
             e3.step()
         torch.cuda.synchronize()
         assert (a - e3.P.flat.cpu()).norm() / a.norm() < 2e-5
-        # collectives captured INTO one graph; without the env override a cross-rank trial decides
+        # RCCL collectives captured INTO one graph: only on request (the default for RCCL is the split schedule, which
+        # cannot race with the process group's watchdog); a cross-rank trial then checks that the capture works
         monkeypatch.delenv("DRL_GRAPH_COLLECTIVES")
+        assert dist.graph_collectives is False and any("split" in f for f in dist.fallbacks)
+        monkeypatch.setenv("DRL_GRAPH_COLLECTIVES", "1")
         assert dist.graph_collectives is True                   # RCCL captures fine on this stack
         _, _, rep4, e4 = _setup(seed=2, rms_eps=1e-2)
         e4.use_graph = True
