@@ -24,6 +24,7 @@
 #include <ctime>
 #include <fcntl.h>
 #include <new>
+#include <csignal>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -87,13 +88,19 @@ struct alignas(kCacheLine) RingHeader {
     alignas(kCacheLine) std::atomic<uint64_t> pushed;    // committed blocks (stat)
     std::atomic<uint64_t> rejected;                      // try_reserve failures because full (stat)
     std::atomic<uint64_t> epoch;                         // bumped by ring_reset (DEL experience)
+    std::atomic<uint64_t> abandoned;                     // reservations of dead producers skipped by the consumer (stat)
 };
 
 struct alignas(kCacheLine) SlotHeader {
     std::atomic<uint64_t> seq;
     uint64_t nbytes;
     uint64_t tag;           // user tag (block kind / producer id)
+    // who holds the reservation: written by the producer right after it has claimed the ticket, read by the consumer
+    // only when the head slot has stayed reserved-but-uncommitted for longer than the grace period (see try_acquire)
+    std::atomic<uint64_t> owner_pid;
+    std::atomic<uint64_t> owner_ticket;    // ticket + 1 (0 = never reserved)
 };
+static_assert(sizeof(SlotHeader) == kCacheLine, "slot header is one cache line");
 
 struct Ring {
     Mapping map;
@@ -101,6 +108,8 @@ struct Ring {
     uint8_t* slots;
     std::string name;
     bool owner;
+    uint64_t stall_pos = ~0ull, stall_since_ns = 0;      // consumer-local: head ticket seen reserved-but-uncommitted since
+    uint64_t abandon_grace_ns = 2000000000ull;           // how long before the reservation's owner is checked for life
     SlotHeader* slot(uint64_t ticket) const {
         return reinterpret_cast<SlotHeader*>(slots + (ticket & (hdr->n_slots - 1)) * hdr->slot_stride);
     }
@@ -150,11 +159,12 @@ void* drl_ring_create(const char* name, uint64_t n_slots, uint64_t slot_bytes) {
     r->hdr = new (r->map.base) RingHeader();
     r->hdr->n_slots = n; r->hdr->slot_bytes = slot_bytes; r->hdr->slot_stride = stride;
     r->hdr->tail.store(0); r->hdr->head.store(0); r->hdr->pushed.store(0); r->hdr->rejected.store(0);
-    r->hdr->epoch.store(1);
+    r->hdr->epoch.store(1); r->hdr->abandoned.store(0);
     r->slots = static_cast<uint8_t*>(r->map.base) + align_up(sizeof(RingHeader), 4096);
     for (uint64_t i = 0; i < n; ++i) {
         SlotHeader* s = new (r->slots + i * stride) SlotHeader();
         s->seq.store(i, std::memory_order_relaxed); s->nbytes = 0; s->tag = 0;
+        s->owner_pid.store(0, std::memory_order_relaxed); s->owner_ticket.store(0, std::memory_order_relaxed);
     }
     std::atomic_thread_fence(std::memory_order_release);
     r->hdr->magic = kRingMagic;
@@ -194,6 +204,8 @@ void* drl_ring_try_reserve(void* h, uint64_t* ticket_out) {
         int64_t dif = (int64_t)seq - (int64_t)pos;
         if (dif == 0) {
             if (r->hdr->tail.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) {
+                s->owner_pid.store((uint64_t)getpid(), std::memory_order_relaxed);
+                s->owner_ticket.store(pos + 1, std::memory_order_release);
                 *ticket_out = pos;
                 return reinterpret_cast<uint8_t*>(s) + sizeof(SlotHeader);
             }
@@ -229,14 +241,38 @@ int drl_ring_push(void* h, const void* data, uint64_t nbytes, uint64_t tag) {
 
 // Consumer step 1 (single consumer): peek the oldest committed slot. NULL when empty (or when the
 // producer holding the head ticket has reserved but not yet committed).
+//
+// A producer that dies between reserve and commit would wedge the queue for good (the head slot never becomes
+// readable, and restarted actors only ever see "full"). The consumer therefore watches the head ticket: when it has
+// been claimed (tail > head) but uncommitted for longer than the grace period, the reservation's owner is looked up -
+// a live producer wrote its pid and ticket into the slot header microseconds after claiming it - and if that process
+// no longer exists (or died before it could even sign the slot), the slot is skipped as an empty block.
 void* drl_ring_try_acquire(void* h, uint64_t* ticket_out, uint64_t* nbytes_out, uint64_t* tag_out) {
     Ring* r = static_cast<Ring*>(h);
-    uint64_t pos = r->hdr->head.load(std::memory_order_relaxed);
-    SlotHeader* s = r->slot(pos);
-    uint64_t seq = s->seq.load(std::memory_order_acquire);
-    if ((int64_t)seq - (int64_t)(pos + 1) < 0) return nullptr;
-    *ticket_out = pos; *nbytes_out = s->nbytes; *tag_out = s->tag;
-    return reinterpret_cast<uint8_t*>(s) + sizeof(SlotHeader);
+    for (;;) {
+        uint64_t pos = r->hdr->head.load(std::memory_order_relaxed);
+        SlotHeader* s = r->slot(pos);
+        uint64_t seq = s->seq.load(std::memory_order_acquire);
+        if ((int64_t)seq - (int64_t)(pos + 1) >= 0) {
+            r->stall_pos = ~0ull;
+            *ticket_out = pos; *nbytes_out = s->nbytes; *tag_out = s->tag;
+            return reinterpret_cast<uint8_t*>(s) + sizeof(SlotHeader);
+        }
+        if (r->hdr->tail.load(std::memory_order_acquire) <= pos) { r->stall_pos = ~0ull; return nullptr; }   // empty
+        const uint64_t now = now_ns();
+        if (r->stall_pos != pos) { r->stall_pos = pos; r->stall_since_ns = now; return nullptr; }
+        if (now - r->stall_since_ns < r->abandon_grace_ns) return nullptr;
+        const uint64_t ot = s->owner_ticket.load(std::memory_order_acquire);
+        const uint64_t pid = s->owner_pid.load(std::memory_order_relaxed);
+        const bool signed_by_claimant = ot == pos + 1;
+        const bool alive = signed_by_claimant && pid != 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM);
+        if (alive) { r->stall_since_ns = now; return nullptr; }      // slow, not dead: look again after another grace period
+        if (s->seq.load(std::memory_order_acquire) != pos) continue;  // it committed after all
+        r->hdr->abandoned.fetch_add(1, std::memory_order_relaxed);
+        r->hdr->head.store(pos + 1, std::memory_order_relaxed);
+        s->seq.store(pos + r->hdr->n_slots, std::memory_order_release);
+        r->stall_pos = ~0ull;
+    }
 }
 
 // Consumer step 2: hand the slot back to producers.
@@ -255,6 +291,9 @@ uint64_t drl_ring_size(void* h) {
 }
 uint64_t drl_ring_pushed(void* h) { return static_cast<Ring*>(h)->hdr->pushed.load(std::memory_order_relaxed); }
 uint64_t drl_ring_rejected(void* h) { return static_cast<Ring*>(h)->hdr->rejected.load(std::memory_order_relaxed); }
+uint64_t drl_ring_abandoned(void* h) { return static_cast<Ring*>(h)->hdr->abandoned.load(std::memory_order_relaxed); }
+// consumer-side handle only: grace period before a stuck reservation's owner is checked (tests shorten it)
+void drl_ring_set_abandon_grace(void* h, double seconds) { static_cast<Ring*>(h)->abandon_grace_ns = (uint64_t)(seconds * 1e9); }
 
 // Drop everything queued (consumer side; DEL experience at learner start-up, ape_x/replay.py:21).
 uint64_t drl_ring_drain(void* h) {
@@ -365,17 +404,36 @@ void drl_beat_close(void* h, const char* name_to_unlink) {
     delete b;
 }
 
+// role 0 = free; kBeatClaiming = a process is filling the slot in: pid / ident / time are written BEFORE the role is
+// published, so a snapshot never pairs a live role with the previous owner's pid or a zero pid.
+constexpr uint64_t kBeatClaiming = ~0ull;
 int drl_beat_register(void* h, uint64_t pid, uint64_t role, uint64_t ident) {
     Beat* b = static_cast<Beat*>(h);
     for (int i = 0; i < kMaxBeats; ++i) {
         uint64_t expect = 0;
-        if (b->slots[i].role.compare_exchange_strong(expect, role)) {
+        if (b->slots[i].role.compare_exchange_strong(expect, kBeatClaiming)) {
             b->slots[i].pid.store(pid); b->slots[i].ident.store(ident);
             b->slots[i].beats.store(0); b->slots[i].progress.store(0); b->slots[i].last_ns.store(now_ns());
+            b->slots[i].role.store(role, std::memory_order_release);
             return i;
         }
     }
     return -1;
+}
+
+// Supervisor side: free every slot registered by `pid` (a child that was killed never unregisters). Returns the count.
+int drl_beat_free_pid(void* h, uint64_t pid) {
+    Beat* b = static_cast<Beat*>(h);
+    int n = 0;
+    for (int i = 0; i < kMaxBeats; ++i) {
+        const uint64_t role = b->slots[i].role.load(std::memory_order_acquire);
+        if (role != 0 && role != kBeatClaiming && b->slots[i].pid.load() == pid) {
+            b->slots[i].pid.store(0);
+            b->slots[i].role.store(0, std::memory_order_release);
+            ++n;
+        }
+    }
+    return n;
 }
 
 void drl_beat_tick(void* h, int slot, uint64_t progress) {
@@ -399,7 +457,7 @@ int drl_beat_snapshot(void* h, uint64_t* out, int max_rows) {
     uint64_t now = now_ns();
     for (int i = 0; i < kMaxBeats && n < max_rows; ++i) {
         uint64_t role = b->slots[i].role.load(std::memory_order_acquire);
-        if (!role) continue;
+        if (!role || role == kBeatClaiming) continue;
         uint64_t last = b->slots[i].last_ns.load(std::memory_order_acquire);
         out[6 * n + 0] = b->slots[i].pid.load(); out[6 * n + 1] = role; out[6 * n + 2] = b->slots[i].ident.load();
         out[6 * n + 3] = b->slots[i].beats.load(); out[6 * n + 4] = now > last ? now - last : 0;
@@ -411,6 +469,6 @@ int drl_beat_snapshot(void* h, uint64_t* out, int max_rows) {
 
 int drl_shm_unlink(const char* name) { return shm_unlink(name); }
 
-const char* drl_host_version() { return "drl_host 0.1"; }
+const char* drl_host_version() { return "drl_host 0.2"; }
 
 }  // extern "C"

@@ -65,6 +65,9 @@ def _declare_host(lib) -> None:
         "drl_ring_pushed": (c_uint64, [c_void_p]),
         "drl_ring_rejected": (c_uint64, [c_void_p]),
         "drl_ring_drain": (c_uint64, [c_void_p]),
+        "drl_ring_abandoned": (c_uint64, [c_void_p]),
+        "drl_ring_set_abandon_grace": (None, [c_void_p, ctypes.c_double]),
+        "drl_beat_free_pid": (c_int, [c_void_p, c_uint64]),
         "drl_param_create": (c_void_p, [c_char_p, c_uint64]),
         "drl_param_open": (c_void_p, [c_char_p]),
         "drl_param_close": (None, [c_void_p, c_int]),

@@ -32,6 +32,10 @@ class HeartbeatTable:
                      beats=int(buf[6 * i + 3]), age_s=buf[6 * i + 4] / 1e9, progress=int(buf[6 * i + 5]))
                 for i in range(n)]
 
+    def free_pid(self, pid: int) -> int:
+        """Supervisor side: free the slots a dead child registered (it could not unregister itself)."""
+        return int(self._lib.drl_beat_free_pid(self._h, int(pid)))
+
     def close(self):
         if self._h:
             self._lib.drl_beat_close(self._h, self.name.encode() if self._owner else b"")

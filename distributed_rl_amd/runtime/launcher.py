@@ -63,6 +63,18 @@ def build_commands(conf, n_actors: int, server: str, run_id: str, extra_learner:
     return cmds
 
 
+def _free_beats(hb_table, name: str, pid: int) -> None:
+    """Heartbeat rows of a reaped child: its own pid, and for the learner (whose ranks may be grandchildren under
+    torch.distributed.run) every row of role learner."""
+    if hb_table is None:
+        return
+    hb_table.free_pid(pid)
+    if name == "learner":
+        for row in hb_table.snapshot():
+            if row["role"] == "learner":
+                hb_table.free_pid(row["pid"])
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description="distributed_rl_amd launcher")
     ap.add_argument("--num-actors", type=int, default=4)
@@ -72,6 +84,7 @@ def main(argv=None) -> int:
     ap.add_argument("--restart-actors", action="store_true")
     ap.add_argument("--stall-seconds", type=float, default=120.0)
     ap.add_argument("--kill-stalled", action="store_true")
+    ap.add_argument("--watch-period", type=float, default=5.0, help="seconds between two looks at the heartbeat table")
     ap.add_argument("--learner-args", type=str, default="", help="extra flags for learner_node.py (one string)")
     ap.add_argument("--actor-args", type=str, default="", help="extra flags for actor_node.py (one string)")
     ap.add_argument("--timeout", type=float, default=0.0, help="stop everything after this many seconds (0 = never)")
@@ -120,6 +133,7 @@ def main(argv=None) -> int:
                 p.kill()
 
     stop = {"flag": False}
+    restarts: Dict[str, int] = {}
 
     def on_signal(signum, frame):
         stop["flag"] = True
@@ -148,24 +162,41 @@ def main(argv=None) -> int:
                 code = p.poll()
                 if code is None:
                     continue
+                _free_beats(hb_table, name, p.pid)       # a killed child could not unregister its heartbeat slot
                 if name.startswith("actor_") and args.restart_actors and not stop["flag"]:
-                    print("[launcher] %s exited with %s, restarting" % (name, code))
+                    print("[launcher] %s exited with %s, restarting" % (name, code), flush=True)
                     spawn(name)
+                    restarts[name] = restarts.get(name, 0) + 1
                     continue
-                print("[launcher] %s exited with %s, shutting down" % (name, code))     # wait -n semantics
+                print("[launcher] %s exited with %s, shutting down" % (name, code), flush=True)     # wait -n semantics
                 rc = code if name == "learner" or code != 0 else rc
                 stop["flag"] = True
                 break
-            if hb_table is not None and time.time() - last_watch > 5.0:
+            if hb_table is not None and time.time() - last_watch > args.watch_period:
                 last_watch = time.time()
                 for row in hb_table.snapshot():
-                    if row["age_s"] > args.stall_seconds:
-                        print("[launcher] %s %d (pid %d) silent for %.0f s" % (row["role"], row["ident"], row["pid"], row["age_s"]))
-                        if args.kill_stalled:
+                    if row["age_s"] <= args.stall_seconds or row["pid"] <= 0:
+                        continue
+                    # only processes THIS launcher started are ever signalled: the row is mapped back to a child of the
+                    # procs table by role and ident (a stale row's pid may belong to anybody by now)
+                    name = "learner" if row["role"] == "learner" else "actor_%d" % row["ident"] if row["role"] == "actor" else ""
+                    child = procs.get(name)
+                    print("[launcher] %s %d (pid %d) silent for %.0f s" % (row["role"], row["ident"], row["pid"], row["age_s"]),
+                          flush=True)
+                    if child is None or child.poll() is not None:
+                        hb_table.free_pid(row["pid"])    # nobody of ours: a leftover row, drop it
+                        continue
+                    if args.kill_stalled:
+                        print("[launcher] terminating stalled %s (pid %d)" % (name, child.pid), flush=True)
+                        try:
+                            child.send_signal(signal.SIGCONT)        # a stopped process would not see the SIGTERM
+                            child.terminate()
                             try:
-                                os.kill(row["pid"], signal.SIGTERM)
-                            except ProcessLookupError:
-                                pass
+                                child.wait(5)
+                            except subprocess.TimeoutExpired:
+                                child.kill()
+                        except ProcessLookupError:
+                            pass
     finally:
         teardown()
         if hb_table is not None:

@@ -51,7 +51,12 @@ def load_checkpoint(path: str, policy, target=None, optimizer=None) -> int:
     step = 0
     aux_path = path[:-4] + ".aux.pth"
     if os.path.exists(aux_path):
-        aux = torch.load(aux_path, map_location="cpu", weights_only=False)   # file written by this framework
+        # the sidecar holds only tensors, containers and primitives (optimizer.state_dict() is such a nest), so the
+        # restricted unpickler loads it; anything else next to a checkpoint is refused, never executed
+        try:
+            aux = torch.load(aux_path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            raise RuntimeError("refusing to load %s: not a plain tensor / primitive sidecar (%s)" % (aux_path, e)) from e
         step = int(aux.get("step", 0))
         if target is not None and "target" in aux:
             target.load_state_dict(aux["target"])

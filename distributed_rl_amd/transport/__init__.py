@@ -152,9 +152,13 @@ class ShmExperience(ExperienceChannel):
     def acquire(self):
         """Zero-copy consumer access: returns ``(ticket, decoded views)`` or None. Call :meth:`release`."""
         t, nb, tag = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        ptr = self._lib.drl_ring_try_acquire(self._h, ctypes.byref(t), ctypes.byref(nb), ctypes.byref(tag))
-        if not ptr:
-            return None
+        while True:
+            ptr = self._lib.drl_ring_try_acquire(self._h, ctypes.byref(t), ctypes.byref(nb), ctypes.byref(tag))
+            if not ptr:
+                return None
+            if nb.value >= codec.HEADER_BYTES:
+                break
+            self._lib.drl_ring_release(self._h, t.value)      # an empty commit (a producer that gave up its reservation)
         buf = (ctypes.c_ubyte * nb.value).from_address(ptr)
         return t.value, codec.decode(buf)
 
@@ -177,7 +181,12 @@ class ShmExperience(ExperienceChannel):
 
     def stats(self):
         return dict(size=self.size(), pushed=int(self._lib.drl_ring_pushed(self._h)),
-                    rejected=int(self._lib.drl_ring_rejected(self._h)))
+                    rejected=int(self._lib.drl_ring_rejected(self._h)), abandoned=int(self._lib.drl_ring_abandoned(self._h)))
+
+    def set_abandon_grace(self, seconds: float) -> None:
+        """Consumer side: how long the head slot may stay reserved-but-uncommitted before its owner is checked for life
+        (a producer killed between reserve and commit; csrc/host/drl_host.cpp drl_ring_try_acquire)."""
+        self._lib.drl_ring_set_abandon_grace(self._h, float(seconds))
 
     def reset(self):
         self._lib.drl_ring_drain(self._h)

@@ -1,0 +1,159 @@
+"""Fault injection (the reference has only `trap kill` + `wait -n`, run.sh:3,44): a producer killed in the
+middle of a ring write, stale heartbeat rows, an actor SIGKILLed under --restart-actors, an actor SIGSTOPped under
+--kill-stalled. Real processes, CPU only."""
+import os
+import re
+import signal
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from distributed_rl_amd.runtime.heartbeat import HeartbeatTable
+from distributed_rl_amd.transport import ShmExperience, codec, shm_names
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _block(n=2, seed=0):
+    rng = np.random.default_rng(seed)
+    return dict(state=rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8),
+                next_state=rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8),
+                action=np.arange(n, dtype=np.int32), reward=np.ones(n, np.float32), done=np.zeros(n, np.float32),
+                prio=np.ones(n, np.float32))
+
+
+def test_ring_skips_reservation_of_dead_producer(run_id):
+    """A producer that dies between reserve and commit must not wedge the single-consumer ring: the consumer
+    skips the slot once its owner is gone; blocks committed behind it arrive; a LIVE slow producer is never skipped."""
+    name = shm_names(run_id)[0]
+    ring = ShmExperience(name, create=True, n_slots=4, slot_bytes=1 << 20)
+    try:
+        ring.set_abandon_grace(0.2)
+        code = ("import ctypes,os,sys; sys.path.insert(0,%r)\n"
+                "from distributed_rl_amd.transport import ShmExperience\n"
+                "r = ShmExperience(%r)\n"
+                "t = ctypes.c_uint64()\n"
+                "assert r._lib.drl_ring_try_reserve(r._h, ctypes.byref(t))\n"
+                "os._exit(0)\n") % (ROOT, name)
+        subprocess.run([sys.executable, "-c", code], check=True, timeout=60)
+        assert ring.size() == 1 and ring.drain() == []                 # reserved, never committed
+        assert ring.push(_block(seed=1), codec.KIND_APEX, 7, 0)        # a healthy producer queues behind it
+        assert ring.drain() == []                                      # first look: the stall clock starts
+        time.sleep(0.3)
+        got = ring.drain()
+        assert len(got) == 1 and np.array_equal(got[0]["state"], _block(seed=1)["state"])
+        assert ring.stats()["abandoned"] == 1
+        # a live producer that is merely slow keeps its slot
+        import ctypes
+        t = ctypes.c_uint64()
+        assert ring._lib.drl_ring_try_reserve(ring._h, ctypes.byref(t))
+        assert ring.drain() == []
+        time.sleep(0.3)
+        assert ring.drain() == [] and ring.stats()["abandoned"] == 1
+        ring._lib.drl_ring_commit(ring._h, t.value, 0, 0)              # ... and may still commit (an empty block here)
+        # the ring keeps working for a full lap afterwards
+        for k in range(6):
+            assert ring.push(_block(seed=k), codec.KIND_APEX, 1, k)
+            while True:
+                got = ring.acquire()
+                if got is None:
+                    break
+                ring.release(got[0])
+        assert ring.size() == 0
+    finally:
+        ring.close()
+
+
+def test_heartbeat_rows_of_dead_children_are_freed(run_id):
+    tab = HeartbeatTable(shm_names(run_id)[2], create=True)
+    try:
+        hb = tab.register("actor", 3)
+        hb.tick(10)
+        rows = tab.snapshot()
+        assert len(rows) == 1 and rows[0]["pid"] == os.getpid() and rows[0]["role"] == "actor" and rows[0]["ident"] == 3
+        assert tab.free_pid(os.getpid()) == 1 and tab.snapshot() == []
+        assert tab.free_pid(os.getpid()) == 0
+        again = tab.register("learner", 0)                              # the slot is reusable
+        assert again.slot == hb.slot and tab.snapshot()[0]["pid"] == os.getpid()
+    finally:
+        tab.close()
+
+
+def _launch(run_id, tmp_path, extra, learner_steps=40):
+    save = tmp_path / "models"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", DRL_NUM_ENVS="2")
+    cmd = [sys.executable, "-u", "-m", "distributed_rl_amd.runtime.launcher", "--num-actors", "2", "--conf", "config/all.conf",
+           "--run-id", run_id, "--timeout", "240",
+           "--learner-args", "--max-steps %d --batch-size 16 --start-memory-size 600 --save-timing 1000 --save-dir %s --quiet "
+                             "--device cpu" % (learner_steps, save),
+           "--actor-args", "--quiet --device cpu --actor-batch 16"] + extra
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = []
+    th = threading.Thread(target=lambda: [lines.append(ln) for ln in p.stdout], daemon=True)
+    th.start()
+    return p, lines, th
+
+
+def _actor_pid(run_id, ident, timeout=120, exclude=None):
+    """pid of actor ``ident`` from the heartbeat table, once it has started ticking."""
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            tab = HeartbeatTable(shm_names(run_id)[2], create=False)
+        except OSError:
+            time.sleep(0.2)
+            continue
+        try:
+            for row in tab.snapshot():
+                if row["role"] == "actor" and row["ident"] == ident and row["beats"] > 0 and row["pid"] != exclude:
+                    return row["pid"]
+        finally:
+            tab._lib.drl_beat_close(tab._h, b"")
+            tab._h = None
+        time.sleep(0.2)
+    raise AssertionError("actor %d never registered a heartbeat" % ident)
+
+
+def test_sigkill_actor_is_restarted_and_learner_finishes(tmp_path, run_id):
+    p, lines, th = _launch(run_id, tmp_path, ["--restart-actors"])
+    try:
+        pid = _actor_pid(run_id, 2)
+        os.kill(pid, signal.SIGKILL)                                    # fault: an actor dies mid-run
+        rc = p.wait(timeout=300)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    th.join(10)
+    out = "".join(lines)
+    assert re.search(r"actor_2 exited with -9, restarting", out), out[-3000:]
+    assert "learner exited with 0" in out and rc == 0, out[-3000:]       # the learner reached its step budget regardless
+
+
+def test_sigstop_actor_is_killed_as_stalled_and_restarted(tmp_path, run_id):
+    p, lines, th = _launch(run_id, tmp_path, ["--restart-actors", "--kill-stalled", "--stall-seconds", "3", "--watch-period", "1"],
+                           learner_steps=200)
+    try:
+        pid = _actor_pid(run_id, 1)
+        os.kill(pid, signal.SIGSTOP)                                    # fault: an actor hangs (no more heartbeats)
+        t0 = time.time()
+        while time.time() - t0 < 120 and not any("terminating stalled actor_1" in ln for ln in lines):
+            time.sleep(0.2)
+        new_pid = _actor_pid(run_id, 1, exclude=pid)                                 # a fresh actor_1 is ticking again
+        rc = p.wait(timeout=300)
+    finally:
+        if p.poll() is None:
+            p.kill()
+        try:
+            os.kill(pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+    th.join(10)
+    out = "".join(lines)
+    assert "terminating stalled actor_1" in out, out[-3000:]
+    assert re.search(r"actor_1 exited with -?\d+, restarting", out), out[-3000:]
+    assert new_pid != pid
+    assert "learner exited with 0" in out and rc == 0, out[-3000:]
