@@ -3,7 +3,8 @@
 max over the last two returned frames, reset = 4 copies + ``randint(1,30)//4`` no-ops, episode cap.
 
 Only imported when gym + an Atari backend are installed (they are not in the MI355X image), so
-this module must never be imported unconditionally. Frames stay uint8 (the reference divides by
+this module must never be imported unconditionally. tests/test_plugins_fakes.py pins it to the reference wrapper's
+arithmetic over a scripted in-tree AtariEnv (parity with the real emulator unpinned). Frames stay uint8 (the reference divides by
 255 on the host, utils.py:34; here that is fused into the conv1 kernel).
 """
 from __future__ import annotations
@@ -65,6 +66,11 @@ class AtariVecEnv:
 
     def current_obs(self):
         return self.obs.copy()
+
+    def render_rgb(self, i: int = 0) -> np.ndarray:
+        """The emulator's RGB screen of env ``i`` as CHW uint8 - what the reference's actors send to their visdom
+        window every step (``env.env._get_image()``, ape_x/actor.py:46,82)."""
+        return np.ascontiguousarray(np.asarray(self.envs[i]._get_image(), dtype=np.uint8).transpose(2, 0, 1))
 
     def step(self, action):
         reward = np.zeros(self.E, dtype=np.float32)

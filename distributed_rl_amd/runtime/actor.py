@@ -237,7 +237,8 @@ class Actor:
                         self.metrics.scalar("Score %s" % self.name, self.episodes, scores[e])
                     scores[e] = 0.0
             if self.metrics is not None and self.render_every and t % self.render_every == 0:
-                self.metrics.image("Frame %s" % self.name, obs[0][..., -1])
+                rgb = getattr(self.env, "render_rgb", None)          # emulator screen when there is one, else the newest plane
+                self.metrics.image("Frame %s" % self.name, rgb(0) if rgb is not None else obs[0][..., -1])
             while len(self.local) >= cfg.actor_batch:
                 self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
             t += 1

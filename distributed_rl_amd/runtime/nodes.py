@@ -91,6 +91,9 @@ def actor_main(argv=None) -> int:
     parser.add_argument('--param-period', type=int, default=None)
     parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
                         help='hip = batched gfx950 inference engine (Ape-X and R2D2; needs a GPU).')
+    parser.add_argument('--render-every', type=int, default=0,
+                        help="Send env 0's screen to the metrics sinks every N env steps (0 = never). The reference sends one "
+                             "frame per step over HTTP (ape_x/actor.py:82); here it is opt-in and rate-limited.")
     parser.add_argument('--learner-ranks', type=int, default=int(os.environ.get('DRL_LEARNER_RANKS', '1')),
                         help='Number of data-parallel learner ranks; actor i feeds the shard of rank (i-1) %% ranks.')
     _common(parser)
@@ -125,7 +128,7 @@ def actor_main(argv=None) -> int:
             eps = epsilon_ladder(args.num_envs, (args.no - 1) * args.num_envs + 1, args.num_total_actors * args.num_envs)
             engine = ActorEngine(env.n_action, args.num_envs, device, eps=eps, seed=args.seed or args.no, init_model=net)
         actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, device, heartbeat=hb, seed=args.seed,
-                      engine=engine)
+                      engine=engine, render_every=args.render_every)
     else:
         engine = None
         use_hip = args.engine == 'hip' or (args.engine == 'auto' and device.type == 'cuda')
@@ -138,7 +141,7 @@ def actor_main(argv=None) -> int:
             engine = R2D2ActorEngine(env.n_action, args.num_envs, cfg, device, eps=eps, seed=args.seed or args.no,
                                      init_model=net, done_offset=cfg.nstep if cfg.reference_nstep_order else 0)
         actor = Actor(args.no, env, net, cfg, exp, par, metrics, args.num_total_actors, 'cpu' if use_hip else device,
-                      target_net=tgt, heartbeat=hb, seed=args.seed, engine=engine)
+                      target_net=tgt, heartbeat=hb, seed=args.seed, engine=engine, render_every=args.render_every)
     actor.pull_params()
     try:
         actor.run(max_steps=args.max_steps)

@@ -3,6 +3,7 @@
 Only usable when the ``redis`` Python module and a server are present (neither is in the MI355X
 image); kept so multi-node CPU actor fleets can still feed a learner over TCP exactly like the
 reference deployment (README.md:14-19). Payloads are this framework's binary blocks, not pickles.
+Executed in tests/test_plugins_fakes.py against an in-tree fake of the module (real-server parity unpinned).
 """
 from __future__ import annotations
 
@@ -33,9 +34,12 @@ class RedisExperience(ExperienceChannel):
         return True
 
     def drain(self, max_blocks=1 << 30):
-        pipe = self._c.pipeline()                    # atomic drain, replay.py:26-29
+        # atomic drain (MULTI/EXEC), replay.py:26-29. The reference trims with LTRIM -1 0, which empties a list of n > 1
+        # elements but KEEPS a single one (start = stop = 0), so a lone blob is delivered again on every poll until a second
+        # one arrives; DEL inside the same transaction has the intended at-most-once semantics.
+        pipe = self._c.pipeline()
         pipe.lrange(self.KEY, 0, -1)
-        pipe.ltrim(self.KEY, -1, 0)
+        pipe.delete(self.KEY)
         data = pipe.execute()[0] or []
         return [codec.decode(d, copy=True) for d in data]
 
