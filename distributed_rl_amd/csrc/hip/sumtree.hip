@@ -81,13 +81,17 @@ __global__ __launch_bounds__(256) void k_rebuild_upper(TreeDesc tr, int n2_block
     tree_rebuild_upper_block(tr, n2_blocks, st_end, blockIdx.x, red);
 }
 
-// Ring ingest: slots [start, start+n) mod cap get new priorities and a new generation.
+// Ring ingest: slots [start, start+n) mod cap get new priorities and a new generation. prio == nullptr RETIRES the
+// slots (priority 0: they cannot be drawn any more while their data is overwritten asynchronously; engine/ingest.py).
+// The live item count (a device scalar read by the sampler) rides along instead of costing a launch of its own.
 __global__ void k_ingest(TreeDesc tr, long long start, int n, const float* __restrict__ prio,
-                         int* __restrict__ gen, int* __restrict__ idx_out) {
+                         int* __restrict__ gen, int* __restrict__ idx_out, long long* __restrict__ n_items_out,
+                         long long n_items_val) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && n_items_out) *n_items_out = n_items_val;
     if (i >= n) return;
     long long s = (start + i) % tr.cap;
-    tr.base[tr.off[0] + s] = prio[i];
+    tr.base[tr.off[0] + s] = prio ? prio[i] : 0.f;
     if (gen) gen[s] += 1;
     idx_out[i] = (int)s;
 }
@@ -149,10 +153,11 @@ DRL_API int drl_sumtree_update(float* base, int n_levels, const long long* off, 
 }
 
 DRL_API int drl_sumtree_ingest(float* base, int n_levels, const long long* off, long long cap, long long start, int n,
-                               const float* prio, int* gen, int* idx_scratch, hipStream_t s) {
+                               const float* prio, int* gen, int* idx_scratch, long long* n_items_out,
+                               long long n_items_val, hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0 || n > cap) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
-    k_ingest<<<(n + 255) / 256, 256, 0, s>>>(d, start, n, prio, gen, idx_scratch);
+    k_ingest<<<(n + 255) / 256, 256, 0, s>>>(d, start, n, prio, gen, idx_scratch, n_items_out, n_items_val);
     if (n_levels > 1) k_fix_level<<<(n + 3) / 4, 256, 0, s>>>(d, 1, idx_scratch, n);
     rebuild_upper(d, nullptr, s);
     return (int)hipGetLastError();

@@ -1,14 +1,19 @@
 """GPU learner process: the runtime around ApexEngine / R2D2Engine (replaces Learner.optimize_loop +
 the Replay thread of the reference, ape_x/learner.py:57-99, ape_x/replay.py:24-35, on an MI355X).
 
-Loop: bounded ingest from the experience channel straight into the HBM replay (no sleep-based back-pressure,
-SURVEY M5) → one graph replay per learner step → every ``publish_period`` steps / ``publish_interval`` seconds
-publish the flat fp32 parameters (versioned register; RCCL broadcast across GPUs) → periodic checkpoint in the
+Loop: ``AsyncIngest.service()`` (engine/ingest.py: a host thread stages experience blocks into pinned memory, a side
+HIP stream DMAs them into the HBM replay while the learner keeps stepping; only two tiny tree launches per block touch
+the learner stream - no sleep-based back-pressure) → one graph replay per learner step → every
+``publish_period`` steps / ``publish_interval`` seconds publish the flat fp32 parameters (a D2D snapshot on the learner
+stream, D2H + register write on a side stream / thread: the loop never waits for PCIe) → periodic checkpoint in the
 reference's ``model_<t>.pth`` format (+ sidecar with optimizer moments, target net and step so ``--resume`` works).
+Wall-clock phase timers (ingest / step / publish / save) and the ingest counters go to the metrics sinks every
+``fit_timing`` steps.
 """
 from __future__ import annotations
 
 import os
+import threading
 import time
 from typing import Optional
 
@@ -17,6 +22,72 @@ import torch
 from ..config import ApexConfig, R2D2Config
 from ..models import DuelingDQN, DuelingLSTMDQN
 from ..transport import ExperienceChannel, ParamChannel
+
+
+class _AsyncPublisher:
+    """Parameter publication off the learner's critical path: ``publish()`` snapshots the flat fp32 parameters with one
+    D2D copy on the learner stream (a consistent version, ~10 us), a side stream moves the snapshot into pinned memory
+    and a thread writes it into the parameter channel once that copy has completed. A publication that is still in
+    flight is not queued behind: the register is a latest-value register, the next period publishes."""
+
+    def __init__(self, flat: torch.Tensor, params: ParamChannel):
+        self.flat, self.params = flat, params
+        self.snap = torch.empty_like(flat)
+        self.host = torch.empty(flat.numel(), dtype=torch.float32).pin_memory()
+        self.stream = torch.cuda.Stream(flat.device)
+        self._busy = threading.Event()
+        self._go = threading.Event()
+        self._stop = False
+        self._done_ev = None
+        self.version = 0
+        self.skipped = 0
+        self.error = None
+        self._th = threading.Thread(target=self._run, name="drl-publish", daemon=True)
+        self._th.start()
+
+    def _run(self) -> None:
+        while True:
+            self._go.wait()
+            self._go.clear()
+            if self._stop:
+                return
+            try:
+                self._done_ev.synchronize()
+                self.version = self.params.publish(self.host.numpy())
+            except BaseException as e:  # noqa: BLE001
+                self.error = e
+            finally:
+                self._busy.clear()
+
+    def publish(self, wait: bool = False) -> int:
+        if self.error is not None:
+            raise RuntimeError("parameter publisher died") from self.error
+        if self._busy.is_set():
+            if not wait:
+                self.skipped += 1
+                return self.version
+            while self._busy.is_set():
+                time.sleep(0.0005)
+        self._busy.set()
+        cur = torch.cuda.current_stream(self.flat.device)
+        self.snap.copy_(self.flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            self.host.copy_(self.snap, non_blocking=True)
+            self._done_ev = torch.cuda.Event()
+            self._done_ev.record(self.stream)
+        self._go.set()
+        if wait:
+            while self._busy.is_set():
+                time.sleep(0.0005)
+        return self.version
+
+    def close(self) -> None:
+        self._stop = True
+        self._go.set()
+        self._th.join(2.0)
 
 
 class HipLearner:
@@ -45,6 +116,17 @@ class HipLearner:
         self.step = 0
         self._last_pub = 0.0
         self.ingested = 0
+        self.pipe = None
+        self._pub = None
+        if self.device.type == "cuda" and os.environ.get("DRL_ASYNC_INGEST", "1") != "0":
+            from .ingest import AsyncIngest
+            self.pipe = AsyncIngest(exp, self.replay, self.device)
+            self._pub = _AsyncPublisher(self.engine.P.flat, params)
+        if self.metrics is None:
+            from ..obs import Metrics
+            self.metrics_local = Metrics([])
+        else:
+            self.metrics_local = self.metrics
 
     def _fit_capacity(self, want: int, cfg) -> int:
         """The replay lives in HBM: clamp the requested item count to what fits next to the engine's activations (75 %
@@ -66,15 +148,27 @@ class HipLearner:
 
     # ---- pieces -------------------------------------------------------------------------------------
     def ingest(self, max_blocks: Optional[int] = None) -> int:
-        n = 0
-        for blk in self.exp.drain(max_blocks or self.max_blocks):
-            n += self.replay.ingest_block(blk)
+        """One ingest turn between two learner steps; returns the number of items that became sampleable."""
+        if self.pipe is not None:
+            n = self.pipe.service()
+        else:                           # synchronous fallback (DRL_ASYNC_INGEST=0, CPU tests of this class)
+            n = 0
+            for blk in self.exp.drain(max_blocks or self.max_blocks):
+                n += self.replay.ingest_block(blk)
         self.ingested += n
         return n
 
-    def publish(self) -> int:
+    def publish(self, wait: bool = False) -> int:
         self._last_pub = time.time()
+        if self._pub is not None:
+            return self._pub.publish(wait=wait)
         return self.params.publish(self.engine.P.flat.cpu().numpy())
+
+    def close(self) -> None:
+        if self.pipe is not None:
+            self.pipe.close()
+        if self._pub is not None:
+            self._pub.close()
 
     def save(self, save_dir: str) -> str:
         os.makedirs(save_dir, exist_ok=True)
@@ -114,7 +208,7 @@ class HipLearner:
         t0 = time.time()
         while len(self.replay) <= n:
             if self.ingest(64) == 0:
-                time.sleep(0.01)
+                time.sleep(0.001 if self.pipe is not None else 0.01)
             if timeout is not None and time.time() - t0 > timeout:
                 return False
             if self.heartbeat is not None:
@@ -132,15 +226,19 @@ class HipLearner:
             # xGMI all-reduce polls its peers for at most DRL_XGMI_TIMEOUT_S), so the ranks start them together
             self.dist.barrier()
         end = None if max_steps is None else self.step + max_steps
-        t_last, n_last = time.time(), self.step
+        t_last, n_last, i_last = time.time(), self.step, self.ingested
         while end is None or self.step < end:
             if stop_event is not None and stop_event.is_set():
                 break
             t = self.step
-            self.ingest()
-            self.engine.step()
+            ph = self.metrics_local.phase
+            with ph("learner/ingest"):
+                self.ingest()
+            with ph("learner/step"):
+                self.engine.step()
             if t % cfg.publish_period == 0 and time.time() - self._last_pub >= self.publish_interval:
-                self.publish()
+                with ph("learner/publish"):
+                    self.publish()
             if t % cfg.fit_timing == 0:
                 now = time.time()
                 if self.metrics is not None:
@@ -149,14 +247,30 @@ class HipLearner:
                     self.metrics.scalar("Memory size", t, len(self.replay), force=True)
                     if t > n_last:
                         self.metrics.scalar("Updates per second", t, (t - n_last) / max(1e-9, now - t_last), force=True)
-                t_last, n_last = now, t
+                        self.metrics.scalar("Ingested items per second", t, (self.ingested - i_last) / max(1e-9, now - t_last),
+                                            force=True)
+                    self._report_runtime(t)
+                t_last, n_last, i_last = now, t, self.ingested
                 if self.heartbeat is not None:
                     self.heartbeat.tick(t)
             if t % cfg.save_timing == 0 and (self.dist is None or self.dist.rank == 0):        # one writer
-                self.save(save_model_dir)
+                with ph("learner/save"):
+                    self.save(save_model_dir)
             self.step += 1
         torch.cuda.synchronize(self.device)
         return self.step
+
+    def _report_runtime(self, t: int) -> None:
+        """Ring fill / rejects, ingest backlog and the wall-clock share of every loop phase -> metrics sinks (JSONL)."""
+        m = self.metrics
+        if hasattr(self.exp, "stats"):
+            rs = self.exp.stats()
+            m.scalar("Ring fill", t, rs["size"], force=True)
+            m.scalar("Ring rejected pushes", t, rs["rejected"], force=True)
+        if self.pipe is not None:
+            m.scalar("Ingest blocks in flight", t, self.pipe.pending(), force=True)
+        for name, rep in self.metrics_local.phase_report().items():
+            m.scalar("Phase ms %s" % name, t, rep["mean_ms"], force=True)
 
 
 def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
@@ -172,9 +286,11 @@ def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
         learner.engine.sync_target()
     if args.resume:
         learner.resume(args.resume)
-    learner.publish()
+    learner.publish(wait=True)
     try:
         learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir)
     except KeyboardInterrupt:
         pass
+    finally:
+        learner.close()
     return 0

@@ -87,9 +87,15 @@ class R2D2ActorEngine:
         self.sync_target()
 
     # ---- recurrent state ------------------------------------------------------------------------------
-    def get_state(self) -> Tuple[np.ndarray, np.ndarray]:
-        """fp32 host copies of (h, c) BEFORE the next ``act`` (stored with the sequence, models.py:86-87)."""
-        return self.h.float().cpu().numpy(), self.c.cpu().numpy()
+    def get_state(self, rows: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """fp32 host copies of (h, c) BEFORE the next ``act`` (stored with the sequence, models.py:86-87). ``rows``: only
+        these envs (the ones whose step can start a sequence, VecSequenceAssembler.need_state): one gather + one small
+        device-to-host copy instead of 2 x E x 512 floats on every env step."""
+        if rows is None:
+            return self.h.float().cpu().numpy(), self.c.cpu().numpy()
+        idx = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(self.device, non_blocking=True)
+        both = torch.cat((self.h.index_select(0, idx).float(), self.c.index_select(0, idx)), 1).cpu().numpy()
+        return both[:, :self.Hd], both[:, self.Hd:]
 
     def set_state(self, h: np.ndarray, c: np.ndarray) -> None:
         self.h.copy_(torch.as_tensor(h).to(self.device).to(torch.bfloat16))

@@ -127,12 +127,22 @@ def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: 
                                         _p(gen), _p(gen_expected), _p(end_state), _s()), "sumtree_update")
 
 
-def sumtree_ingest(tree: torch.Tensor, lay: TreeLayout, start: int, prio: torch.Tensor, gen: Optional[torch.Tensor],
-                   idx_scratch: torch.Tensor) -> None:
-    _chk(prio, torch.float32, "prio"); _chk(idx_scratch, torch.int32, "idx_scratch")
-    assert idx_scratch.numel() >= prio.numel()
-    _ck(native.hip().drl_sumtree_ingest(_p(tree), lay.n_levels, lay.c_off, lay.capacity, int(start), prio.numel(), _p(prio),
-                                        _p(gen), _p(idx_scratch), _s()), "sumtree_ingest")
+def sumtree_ingest(tree: torch.Tensor, lay: TreeLayout, start: int, prio: Optional[torch.Tensor], gen: Optional[torch.Tensor],
+                   idx_scratch: torch.Tensor, n: Optional[int] = None, n_items: Optional[torch.Tensor] = None,
+                   n_items_val: int = 0) -> None:
+    """Ring slots [start, start + n) get new priorities and a new generation. ``prio=None`` retires them (priority 0)
+    while their data is being replaced (engine/ingest.py). ``n_items`` (int64 device scalar) is set to ``n_items_val``
+    by the same launch."""
+    n = prio.numel() if n is None else int(n)
+    if prio is not None:
+        _chk(prio, torch.float32, "prio")
+        assert prio.numel() >= n
+    _chk(idx_scratch, torch.int32, "idx_scratch")
+    assert idx_scratch.numel() >= n
+    if n_items is not None:
+        _chk(n_items, torch.int64, "n_items")
+    _ck(native.hip().drl_sumtree_ingest(_p(tree), lay.n_levels, lay.c_off, lay.capacity, int(start), n, _p(prio),
+                                        _p(gen), _p(idx_scratch), _p(n_items), int(n_items_val), _s()), "sumtree_ingest")
 
 
 def gather_rows(src: torch.Tensor, off: torch.Tensor, dst: torch.Tensor, row_bytes: int) -> None:

@@ -76,12 +76,42 @@ class DevicePER:
         return float(self.tree[top:top + 64].sum())
 
     # ---- ingest -----------------------------------------------------------------------------------
+    # Three stages, so that the bulk copy can run on its own stream while the learner keeps stepping (engine/ingest.py):
+    # reserve + retire (the slots leave the tree: nothing samples them any more), write_slots (the data, any stream),
+    # commit (priorities + generation + item count, one launch). ``ingest`` runs the three back to back on one stream.
     def _ring_write(self, dst: torch.Tensor, src: torch.Tensor, start: int) -> None:
         n = src.shape[0]
         first = min(n, self.capacity - start)
-        dst[start:start + first].copy_(src[:first], non_blocking=True)
+        dst[start:start + first].copy_(src[:first], non_blocking=True)       # pinned source: one DMA straight into the ring
         if first < n:
             dst[:n - first].copy_(src[first:], non_blocking=True)
+
+    def reserve(self, K: int) -> int:
+        if K > self.capacity:
+            raise ValueError("block larger than the replay")
+        if K > self._scratch.numel():
+            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
+        s = self.cursor
+        self.cursor = (s + K) % self.capacity
+        return s
+
+    def retire(self, start: int, K: int) -> None:
+        H.sumtree_ingest(self.tree, self.lay, start, None, self.gen, self._scratch, n=K)
+
+    def write_slots(self, start: int, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor,
+                    reward: torch.Tensor, done: torch.Tensor) -> None:
+        K = int(action.shape[0])
+        self._ring_write(self.frames[:self.capacity], state.reshape(K, -1), start)
+        self._ring_write(self.frames[self.capacity:], next_state.reshape(K, -1), start)
+        self._ring_write(self.act, action, start)
+        self._ring_write(self.rew, reward, start)
+        self._ring_write(self.done, done, start)
+
+    def commit(self, start: int, prio: torch.Tensor, K: int) -> None:
+        """``prio``: float32 on the device, at least K elements. The item count rides along with the tree launch."""
+        self.count = min(self.capacity, self.count + K)
+        H.sumtree_ingest(self.tree, self.lay, start, prio, self.gen, self._scratch, n=K, n_items=self.n_items,
+                         n_items_val=self.count)
 
     def ingest(self, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor, reward: torch.Tensor,
                done: torch.Tensor, prio: torch.Tensor) -> int:
@@ -89,21 +119,9 @@ class DevicePER:
         K = int(action.shape[0])
         if K == 0:
             return 0
-        if K > self.capacity:
-            raise ValueError("block larger than the replay")
-        if K > self._scratch.numel():
-            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
-        dev = self.device
-        s = self.cursor
-        self._ring_write(self.frames[:self.capacity], state.reshape(K, -1).to(dev, non_blocking=True), s)
-        self._ring_write(self.frames[self.capacity:], next_state.reshape(K, -1).to(dev, non_blocking=True), s)
-        self._ring_write(self.act, action.to(dev, torch.int32, non_blocking=True), s)
-        self._ring_write(self.rew, reward.to(dev, torch.float32, non_blocking=True), s)
-        self._ring_write(self.done, done.to(dev, torch.float32, non_blocking=True), s)
-        H.sumtree_ingest(self.tree, self.lay, s, prio.to(dev, torch.float32).contiguous(), self.gen, self._scratch)
-        self.cursor = (s + K) % self.capacity
-        self.count = min(self.capacity, self.count + K)
-        self.n_items.fill_(self.count)
+        s = self.reserve(K)
+        self.write_slots(s, state, next_state, action, reward, done)
+        self.commit(s, prio.to(self.device, torch.float32).contiguous(), K)
         return K
 
     def ingest_block(self, block: Dict[str, np.ndarray]) -> int:

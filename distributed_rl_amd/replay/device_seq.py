@@ -59,6 +59,7 @@ class DeviceSequenceReplay:
         top = self.lay.offsets[-1]
         return float(self.tree[top:top + 64].sum())
 
+    # ---- ingest: reserve + retire / write_slots / commit (see replay/device_per.py and engine/ingest.py) ------------
     def _ring_write(self, dst, src, start, per: int = 1) -> None:
         n = src.shape[0] // per
         first = min(n, self.capacity - start)
@@ -66,25 +67,41 @@ class DeviceSequenceReplay:
         if first < n:
             dst[:(n - first) * per].copy_(src[first * per:], non_blocking=True)
 
+    def reserve(self, K: int) -> int:
+        if K > self.capacity:
+            raise ValueError("block larger than the replay")
+        if K > self._scratch.numel():
+            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
+        s = self.cursor
+        self.cursor = (s + K) % self.capacity
+        return s
+
+    def retire(self, start: int, K: int) -> None:
+        H.sumtree_ingest(self.tree, self.lay, start, None, self.gen, self._scratch, n=K)
+
+    def write_slots(self, start: int, frames, action, reward, done, length, h0, c0) -> None:
+        K = int(length.shape[0])
+        self._ring_write(self.frames, frames.reshape(K * self.T, -1), start, per=self.T)
+        self._ring_write(self.act, action, start)
+        self._ring_write(self.rew, reward, start)
+        self._ring_write(self.done, done, start)
+        self._ring_write(self.length, length, start)
+        self._ring_write(self.h0, h0, start)
+        self._ring_write(self.c0, c0, start)
+
+    def commit(self, start: int, prio: torch.Tensor, K: int) -> None:
+        self.count = min(self.capacity, self.count + K)
+        H.sumtree_ingest(self.tree, self.lay, start, prio, self.gen, self._scratch, n=K, n_items=self.n_items,
+                         n_items_val=self.count)
+
     def ingest(self, frames, action, reward, done, length, h0, c0, prio) -> int:
         """K sequences: frames (K,T,…) uint8, action/reward/done (K,T), length (K,), h0/c0 (K,H), prio (K,)."""
         K = int(length.shape[0])
         if K == 0:
             return 0
-        dev, s = self.device, self.cursor
-        if K > self._scratch.numel():
-            self._scratch = torch.zeros(K, dtype=torch.int32, device=dev)
-        self._ring_write(self.frames, frames.reshape(K * self.T, -1).to(dev, non_blocking=True), s, per=self.T)
-        self._ring_write(self.act, action.to(dev, torch.int32, non_blocking=True), s)
-        self._ring_write(self.rew, reward.to(dev, torch.float32, non_blocking=True), s)
-        self._ring_write(self.done, done.to(dev, torch.float32, non_blocking=True), s)
-        self._ring_write(self.length, length.to(dev, torch.int32, non_blocking=True), s)
-        self._ring_write(self.h0, h0.to(dev, torch.float32, non_blocking=True), s)
-        self._ring_write(self.c0, c0.to(dev, torch.float32, non_blocking=True), s)
-        H.sumtree_ingest(self.tree, self.lay, s, prio.to(dev, torch.float32).contiguous(), self.gen, self._scratch)
-        self.cursor = (s + K) % self.capacity
-        self.count = min(self.capacity, self.count + K)
-        self.n_items.fill_(self.count)
+        s = self.reserve(K)
+        self.write_slots(s, frames, action, reward, done, length, h0, c0)
+        self.commit(s, prio.to(self.device, torch.float32).contiguous(), K)
         return K
 
     def ingest_block(self, block: Dict[str, np.ndarray]) -> int:

@@ -25,7 +25,8 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from ..algo.nstep import NStepAssembler, SequenceAssembler, SequenceItem
+from ..algo.nstep import SequenceItem
+from ..algo.vec_assembly import VecNStepAssembler, VecSequenceAssembler
 from ..config import ApexConfig, R2D2Config
 from ..models.packing import ParamPack
 from ..transport import ExperienceChannel, ParamChannel, codec
@@ -33,37 +34,49 @@ from ..utils import epsilon_ladder
 
 
 class _LocalApexBuffer:
+    """Actor-side staging of finished n-step transitions (the reference's ``ReplayMemory(1000)``, ape_x/actor.py:49):
+    preallocated arrays, oldest first; overflow drops the oldest like a bounded deque."""
+
     def __init__(self, capacity: int):
         self.capacity = capacity
-        self.clear()
+        self.n = 0
+        self.state = self.next_state = None
+        self.action = np.zeros(capacity, dtype=np.int32)
+        self.reward = np.zeros(capacity, dtype=np.float32)
+        self.done = np.zeros(capacity, dtype=np.float32)
 
     def clear(self):
-        self.state: List[np.ndarray] = []
-        self.next_state: List[np.ndarray] = []
-        self.action: List[int] = []
-        self.reward: List[float] = []
-        self.done: List[float] = []
+        self.n = 0
+
+    def _drop(self, k: int) -> None:
+        rest = self.n - k
+        for a in (self.state, self.next_state, self.action, self.reward, self.done):
+            a[:rest] = a[k:self.n]
+        self.n = rest
 
     def extend(self, b):
-        self.state.extend(b.state)
-        self.next_state.extend(b.next_state)
-        self.action.extend(b.action.tolist())
-        self.reward.extend(b.reward.tolist())
-        self.done.extend(b.done.tolist())
-        over = len(self.action) - self.capacity
+        k = int(b.action.shape[0])
+        if self.state is None:
+            self.state = np.zeros((self.capacity,) + tuple(b.state.shape[1:]), dtype=np.uint8)
+            self.next_state = np.zeros_like(self.state)
+        if k > self.capacity:
+            b = type(b)(*[x[-self.capacity:] for x in b])
+            k = self.capacity
+        over = self.n + k - self.capacity
         if over > 0:                                      # bounded deque semantics (ReplayMemory(1000), actor.py:49)
-            for lst in (self.state, self.next_state, self.action, self.reward, self.done):
-                del lst[:over]
+            self._drop(over)
+        n = self.n
+        self.state[n:n + k], self.next_state[n:n + k] = b.state, b.next_state
+        self.action[n:n + k], self.reward[n:n + k], self.done[n:n + k] = b.action, b.reward, b.done
+        self.n = n + k
 
     def __len__(self):
-        return len(self.action)
+        return self.n
 
     def take(self, n: int):
-        blk = dict(state=np.stack(self.state[:n]), next_state=np.stack(self.next_state[:n]),
-                   action=np.array(self.action[:n], dtype=np.int32), reward=np.array(self.reward[:n], dtype=np.float32),
-                   done=np.array(self.done[:n], dtype=np.float32))
-        for lst in (self.state, self.next_state, self.action, self.reward, self.done):
-            del lst[:n]
+        blk = dict(state=self.state[:n].copy(), next_state=self.next_state[:n].copy(), action=self.action[:n].copy(),
+                   reward=self.reward[:n].copy(), done=self.done[:n].copy())
+        self._drop(n)
         return blk
 
 
@@ -92,18 +105,25 @@ class Actor:
             self.target.eval()
             self.net.hx = torch.zeros(self.E, self.net.hidden, device=device)
             self.net.cx = torch.zeros(self.E, self.net.hidden, device=device)
-            self.asm = SequenceAssembler(self.E, cfg.nstep, cfg.gamma, cfg.burn_in, cfg.seq_len, cfg.overlap,
-                                         cfg.reference_nstep_order, flush_tail=not cfg.reference_nstep_order)
+            self.asm = VecSequenceAssembler(self.E, cfg.nstep, cfg.gamma, cfg.burn_in, cfg.seq_len, cfg.overlap,
+                                            cfg.reference_nstep_order, flush_tail=not cfg.reference_nstep_order,
+                                            hidden=self.net.hidden)
             self.local: List[SequenceItem] = []
         else:
-            self.asm = NStepAssembler(self.E, cfg.nstep, cfg.gamma, cfg.reference_nstep_order,
-                                      flush_tail=not cfg.reference_nstep_order)
+            self.asm = VecNStepAssembler(self.E, cfg.nstep, cfg.gamma, cfg.reference_nstep_order,
+                                         flush_tail=not cfg.reference_nstep_order)
             self.local = _LocalApexBuffer(cfg.actor_local_capacity)
         self.env_steps = 0
         self.published_blocks = 0
         self.dropped_blocks = 0
         self.episodes = 0
         self.render_every = render_every
+        if metrics is not None:
+            self.timers = metrics
+        else:
+            from ..obs import Metrics
+            self.timers = Metrics([])
+        self.report_interval = float(os.environ.get("DRL_ACTOR_REPORT_S", "2.0"))
 
     # ---- parameters -------------------------------------------------------------------------------
     def pull_params(self) -> bool:
@@ -200,36 +220,64 @@ class Actor:
         self.dropped_blocks += 1
 
     # ---- main loop --------------------------------------------------------------------------------
+    def _recurrent_state_before(self):
+        """(h, c) before the next observation is consumed, for the envs whose step may start a sequence (need_state):
+        a small gather instead of a (2, E, 512) device-to-host copy on every env step."""
+        need = np.nonzero(self.asm.need_state())[0]
+        if len(need) == 0:
+            return None, None
+        if self.engine is not None:
+            return self.engine.get_state(rows=need)
+        idx = torch.from_numpy(need).to(self.net.hx.device)
+        return self.net.hx.detach()[idx].cpu().numpy(), self.net.cx.detach()[idx].cpu().numpy()
+
+    def _report(self, t: int, now: float, t_prev: float, steps_prev: int) -> None:
+        """Actor frames/s, dropped blocks, parameter lag and the per-phase wall clock -> metrics sinks."""
+        m = self.metrics
+        sps = (self.env_steps - steps_prev) / max(1e-9, now - t_prev)
+        m.scalar("Env steps per second %s" % self.name, self.env_steps, sps, force=True)
+        m.scalar("Env frames per second %s" % self.name, self.env_steps, sps * getattr(self.env, "frameskip", 4), force=True)
+        m.scalar("Published blocks %s" % self.name, self.env_steps, self.published_blocks, force=True)
+        m.scalar("Dropped blocks %s" % self.name, self.env_steps, self.dropped_blocks, force=True)
+        try:
+            m.scalar("Param lag %s" % self.name, self.env_steps, self.params.version() - self._version, force=True)
+        except Exception:  # noqa: BLE001 - a channel without a cheap version counter
+            pass
+        for name, rep in self.timers.phase_report().items():
+            if name.startswith("actor/"):
+                m.scalar("Phase ms %s %s" % (name, self.name), self.env_steps, rep["mean_ms"], force=True)
+
     def run(self, max_steps: Optional[int] = None, stop_event=None) -> None:
         cfg = self.cfg
+        ph = self.timers.phase
         self.env.reset()
         scores = np.zeros(self.E)
         t = 0
+        t_rep, steps_rep = time.time(), self.env_steps
         while max_steps is None or t < max_steps:
             if stop_event is not None and stop_event.is_set():
                 break
             obs = self.env.current_obs()
-            if self.is_r2d2:
-                if self.engine is not None:
-                    h_before, c_before = self.engine.get_state()
-                else:
-                    h_before = self.net.hx.detach().cpu().numpy()
-                    c_before = self.net.cx.detach().cpu().numpy()
-            action = self.act(obs)
-            next_obs, reward, done, info = self.env.step(action)
+            with ph("actor/act"):
+                if self.is_r2d2:
+                    h_before, c_before = self._recurrent_state_before()
+                action = self.act(obs)
+            with ph("actor/env"):
+                next_obs, reward, done, info = self.env.step(action)
             scores += reward
             r = self._clip(reward)
-            if self.is_r2d2:
-                self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
-                if done.any():
-                    if self.engine is not None:
-                        self.engine.reset(done)
-                    else:
-                        self.net.reset(torch.from_numpy(done))
-            else:
-                out = self.asm.step(obs, action, r, next_obs, done)
-                if out is not None:
-                    self.local.extend(out)
+            with ph("actor/assemble"):
+                if self.is_r2d2:
+                    self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
+                    if done.any():
+                        if self.engine is not None:
+                            self.engine.reset(done)
+                        else:
+                            self.net.reset(torch.from_numpy(done))
+                else:
+                    out = self.asm.step(obs, action, r, next_obs, done)
+                    if out is not None:
+                        self.local.extend(out)
             if done.any():
                 for e in np.nonzero(done)[0]:
                     self.episodes += 1
@@ -239,11 +287,18 @@ class Actor:
             if self.metrics is not None and self.render_every and t % self.render_every == 0:
                 rgb = getattr(self.env, "render_rgb", None)          # emulator screen when there is one, else the newest plane
                 self.metrics.image("Frame %s" % self.name, rgb(0) if rgb is not None else obs[0][..., -1])
-            while len(self.local) >= cfg.actor_batch:
-                self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
+            with ph("actor/publish"):
+                while len(self.local) >= cfg.actor_batch:
+                    self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
             t += 1
             self.env_steps += self.E
             if t % cfg.actor_param_period == 0:
-                self.pull_params()
+                with ph("actor/params"):
+                    self.pull_params()
             if self.heartbeat is not None and t % 16 == 0:
                 self.heartbeat.tick(self.env_steps)
+            if self.metrics is not None and t % 16 == 0:
+                now = time.time()
+                if now - t_rep >= self.report_interval:
+                    self._report(t, now, t_rep, steps_rep)
+                    t_rep, steps_rep = now, self.env_steps

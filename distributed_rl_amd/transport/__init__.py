@@ -162,6 +162,18 @@ class ShmExperience(ExperienceChannel):
         buf = (ctypes.c_ubyte * nb.value).from_address(ptr)
         return t.value, codec.decode(buf)
 
+    def acquire_raw(self):
+        """Zero-copy consumer access without decoding: ``(ticket, address, used bytes)`` of the oldest committed block, or
+        None. The memory stays valid until :meth:`release` (engine/ingest.py copies it into pinned memory in one go)."""
+        t, nb, tag = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        while True:
+            ptr = self._lib.drl_ring_try_acquire(self._h, ctypes.byref(t), ctypes.byref(nb), ctypes.byref(tag))
+            if not ptr:
+                return None
+            if nb.value >= codec.HEADER_BYTES:
+                return t.value, int(ptr), int(nb.value)
+            self._lib.drl_ring_release(self._h, t.value)      # an empty commit (a producer that gave up its reservation)
+
     def release(self, ticket: int) -> None:
         self._lib.drl_ring_release(self._h, ticket)
 

@@ -78,6 +78,22 @@ def encode(block: Dict[str, np.ndarray], kind: int, actor_id: int = 0, env_steps
     return out
 
 
+def layout(buf):
+    """``(meta, [(name, dtype, shape, byte offset, nbytes), ...])`` of the block in ``buf`` (header only is read)."""
+    mv = memoryview(buf).cast("B")
+    magic, kind, K, T, H, o0, o1, o2, actor_id, env_steps, _ = HEADER.unpack_from(mv, 0)
+    if magic != MAGIC:
+        raise ValueError("bad experience block magic")
+    meta = {"kind": kind, "K": K, "actor_id": actor_id, "env_steps": env_steps}
+    off, out = HEADER_BYTES, []
+    for name, dt, shape in _fields(kind, K, T, H, (o0, o1, o2)):
+        nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+        out.append((name, dt, shape, off, nb))
+        off += _al(nb)
+    meta["bytes"] = off
+    return meta, out
+
+
 def decode(buf, copy: bool = False) -> Dict[str, np.ndarray]:
     """Zero-copy views into ``buf`` (set ``copy=True`` when the buffer will be recycled before use)."""
     mv = memoryview(buf).cast("B")

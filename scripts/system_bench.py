@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Whole-system throughput on ONE GPU box: K actor processes x E envs (batched gfx950 inference, array-based n-step /
+sequence assembly, initial priorities) -> shm MPSC ring -> asynchronous ingest (pinned staging + side-stream DMA) -> HBM
+replay -> graph-captured learner, all running CONCURRENTLY for ``--seconds`` after a warm-up. Prints one JSON line with
+the rates sustained inside that window:
+
+  env_steps_per_s / env_frames_per_s (x4 frameskip), ingested_items_per_s, learner_updates_per_s, ring rejects, actor
+  drops, parameter-version lag, per-phase wall clock of the learner loop.
+
+The reference's equivalent is ``./run.sh N`` watched through visdom (README.md:36-49); actors, Redis and the learner's
+replay thread share nothing but TCP there (ape_x/actor.py:58-102, ape_x/replay.py:24-35, ape_x/learner.py:47-49).
+
+  python scripts/system_bench.py --algorithm ape_x --actors 3 --envs 64 --seconds 10
+"""
+import argparse
+import glob
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+import uuid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _last_values(log_dir):
+    """Last value of every scalar series the actors wrote (JSONL sinks)."""
+    out = {}
+    for p in glob.glob(os.path.join(log_dir, "actor_*.jsonl")):
+        with open(p) as fh:
+            for ln in fh:
+                try:
+                    r = json.loads(ln)
+                except ValueError:
+                    continue
+                out[r["name"]] = r["y"]
+    return out
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algorithm", default="ape_x", choices=["ape_x", "r2d2"])
+    ap.add_argument("--actors", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=64, help="envs per actor process")
+    ap.add_argument("--env", default="SyntheticCatch-v0")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--warmup-seconds", type=float, default=3.0)
+    ap.add_argument("--replay", type=int, default=0, help="replay capacity (0: 200 000 transitions / 4 096 sequences)")
+    ap.add_argument("--actor-engine", default="hip", choices=["hip", "torch"])
+    args = ap.parse_args(argv)
+
+    import torch
+    from distributed_rl_amd import envs
+    from distributed_rl_amd.config import make_config
+    from distributed_rl_amd.engine.learner import HipLearner
+    from distributed_rl_amd.obs import Metrics
+    from distributed_rl_amd.runtime.heartbeat import HeartbeatTable
+    from distributed_rl_amd.transport import connect, shm_names
+
+    r2 = args.algorithm == "r2d2"
+    run_id = "sys" + uuid.uuid4().hex[:8]
+    log_dir = os.path.join("/tmp", "drl_" + run_id)
+    os.makedirs(log_dir, exist_ok=True)
+    cfg = make_config(args.algorithm, start_memory_size=256 if r2 else 4096, fit_timing=1 << 30, save_timing=1 << 30)
+    cap = args.replay or (4096 if r2 else 200_000)
+    slot_mb = 32 if r2 else 8
+    exp, par = connect("shm", run_id, create=True, n_slots=32 if r2 else 64, slot_bytes=slot_mb << 20)
+    hb_table = HeartbeatTable(shm_names(run_id)[2], create=True)
+    n_action = envs.n_action_of(args.env)
+    learner = HipLearner(args.algorithm, n_action, cfg, exp, par, Metrics([]), cap, "cuda", publish_interval=0.05)
+    learner.publish(wait=True)
+
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DRL_ACTOR_REPORT_S="1.0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for i in range(1, args.actors + 1):
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "actor_node.py"), "-n", str(i), "-t", str(args.actors), "-a", args.algorithm,
+             "-e", args.env, "--num-envs", str(args.envs), "--engine", args.actor_engine, "--transport", "shm", "--run-id", run_id,
+             "--log-dir", log_dir, "--quiet", "--seed", str(i)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL,
+            stderr=open(os.path.join(log_dir, "actor_%d.err" % i), "w")))
+    result = {"algorithm": args.algorithm, "actors": args.actors, "envs_per_actor": args.envs, "env": args.env,
+              "actor_engine": args.actor_engine, "replay_capacity": cap}
+    stop = threading.Event()
+    marks = {}
+
+    def actor_steps():
+        return sum(r["progress"] for r in hb_table.snapshot() if r["role"] == "actor")
+
+    def clock():
+        """Marks the start and the end of the measurement window while the learner loop runs in the main thread."""
+        t_begin = time.time()
+        while learner.step < 5 and time.time() - t_begin < 240:      # learn-start reached + graph captured
+            time.sleep(0.05)
+        time.sleep(args.warmup_seconds)
+        marks["a"] = (time.time(), learner.step, learner.ingested, actor_steps(), exp.stats())
+        time.sleep(args.seconds)
+        marks["b"] = (time.time(), learner.step, learner.ingested, actor_steps(), exp.stats())
+        marks["versions"] = par.version()
+        stop.set()
+
+    th = threading.Thread(target=clock, daemon=True)
+    th.start()
+    rc = 0
+    try:
+        learner.optimize_loop(save_model_dir=os.path.join(log_dir, "models"), stop_event=stop, warmup_timeout=240)
+        th.join(5)
+        learner.engine.stats()                               # raises if a bounded in-kernel wait timed out
+        (ta, sa, ia, ea, ra), (tb, sb, ib, eb, rb) = marks["a"], marks["b"]
+        dt = tb - ta
+        last = _last_values(log_dir)
+        lag = [v for k, v in last.items() if k.startswith("Param lag")]
+        drops = [v for k, v in last.items() if k.startswith("Dropped blocks")]
+        result.update({
+            "window_s": dt,
+            "learner_updates_per_s": (sb - sa) / dt,
+            "learner_items_per_s": (sb - sa) * cfg.batch_size / dt,
+            "ingested_items_per_s": (ib - ia) / dt,
+            "env_steps_per_s": (eb - ea) / dt,
+            "env_frames_per_s": 4 * (eb - ea) / dt,
+            "ring_blocks_pushed": rb["pushed"] - ra["pushed"],
+            "ring_rejected_pushes": rb["rejected"] - ra["rejected"],
+            "ring_fill_at_end": rb["size"],
+            "actor_dropped_blocks": sum(drops),
+            "param_versions_published": marks["versions"],
+            "param_version_lag_max": max(lag) if lag else None,
+            "replay_items": len(learner.replay),
+            "ingest": learner.pipe.stats() if learner.pipe is not None else "synchronous",
+            "learner_phase_ms": {k: round(v["mean_ms"], 4) for k, v in learner.metrics_local.phase_report().items()},
+            "actor_phase_ms": {k.split(" ", 2)[2]: round(v, 3) for k, v in last.items() if k.startswith("Phase ms actor/")
+                               and k.endswith("actor_1")},
+        })
+    except Exception as e:  # noqa: BLE001
+        result["error"] = repr(e)[:300]
+        rc = 1
+    finally:
+        stop.set()
+        for p in procs:
+            p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        if rc:
+            for i in range(1, args.actors + 1):
+                try:
+                    result.setdefault("actor_stderr", []).append(open(os.path.join(log_dir, "actor_%d.err" % i)).read()[-400:])
+                except OSError:
+                    pass
+        learner.close()
+        exp.close()
+        par.close()
+        hb_table.close()
+    print(json.dumps(result), flush=True)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

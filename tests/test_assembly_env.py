@@ -1,6 +1,7 @@
 """n-step / sequence assembly (ape_x/actor.py:60-90, r2d2/actor.py:26-75) and the synthetic env contract
 (wrapped_env.py:30-47)."""
 import numpy as np
+import pytest
 
 from distributed_rl_amd import envs
 from distributed_rl_amd.algo.nstep import NStepAssembler, SequenceAssembler
@@ -118,3 +119,62 @@ def test_catch_env_contract():
     s2, r, d, _ = single.step(0)
     assert s2.shape == (4, 84, 84)
     assert len(envs.REGISTRY) >= 120 and "SingleFrameMsPacman-v0" in envs.REGISTRY
+
+
+# ---- array-based assemblers (algo/vec_assembly.py) against the per-env oracle above ---------------------------------
+def _episodes(rng, E, steps, p_done):
+    for t in range(steps):
+        yield (rng.integers(0, 256, (E, 6, 6, 2), dtype=np.uint8), rng.integers(0, 4, E), rng.standard_normal(E).astype(np.float32),
+               rng.integers(0, 256, (E, 6, 6, 2), dtype=np.uint8), rng.random(E) < p_done)
+
+
+@pytest.mark.parametrize("n,ref_order,flush", [(3, False, True), (3, True, False), (1, False, True), (5, False, True)])
+def test_vec_nstep_assembler_equals_per_env_oracle(n, ref_order, flush):
+    from distributed_rl_amd.algo.nstep import NStepAssembler
+    from distributed_rl_amd.algo.vec_assembly import VecNStepAssembler
+    E = 7
+    a, b = NStepAssembler(E, n, 0.9, ref_order, flush), VecNStepAssembler(E, n, 0.9, ref_order, flush)
+    rng = np.random.default_rng(n)
+    emitted = 0
+    for s, act, r, s2, d in _episodes(rng, E, 200, 0.08):
+        oa, ob = a.step(s, act, r, s2, d), b.step(s, act, r, s2, d)
+        assert (oa is None) == (ob is None)
+        if oa is None:
+            continue
+        emitted += len(oa.env)
+        key = lambda o: np.lexsort((o.reward, o.env))                 # noqa: E731 - same multiset, any order
+        ka, kb = key(oa), key(ob)
+        assert np.array_equal(oa.env[ka], ob.env[kb]) and np.array_equal(oa.action[ka], ob.action[kb])
+        np.testing.assert_allclose(oa.reward[ka], ob.reward[kb], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(oa.done[ka], ob.done[kb])
+        assert np.array_equal(oa.state[ka], ob.state[kb]) and np.array_equal(oa.next_state[ka], ob.next_state[kb])
+    assert emitted > 500
+
+
+@pytest.mark.parametrize("n,ref_order,flush,lazy", [(2, False, True, True), (2, True, False, False), (3, False, True, False)])
+def test_vec_sequence_assembler_equals_per_env_oracle(n, ref_order, flush, lazy):
+    from distributed_rl_amd.algo.nstep import SequenceAssembler
+    from distributed_rl_amd.algo.vec_assembly import VecSequenceAssembler
+    E, Hd = 5, 8
+    kw = dict(burn_in=3, seq_len=6, overlap=2, reference_order=ref_order, flush_tail=flush)
+    a, b = SequenceAssembler(E, n, 0.9, **kw), VecSequenceAssembler(E, n, 0.9, hidden=Hd, **kw)
+    rng = np.random.default_rng(7)
+    emitted, short, needed = 0, 0, 0
+    for s, act, r, _, d in _episodes(rng, E, 400, 0.03):
+        h, c = rng.standard_normal((E, Hd)).astype(np.float32), rng.standard_normal((E, Hd)).astype(np.float32)
+        oa = a.step(s, act, r, d, h, c)
+        need = b.need_state()
+        needed += int(need.sum())
+        ob = b.step(s, act, r, d, h[need], c[need]) if lazy else b.step(s, act, r, d, h, c)
+        assert len(oa) == len(ob)
+        sa = sorted(oa, key=lambda q: (q.length, float(q.reward.sum())))
+        sb = sorted(ob, key=lambda q: (q.length, float(q.reward.sum())))
+        for x, y in zip(sa, sb):
+            emitted += 1
+            short += x.length < a.total
+            assert x.length == y.length and np.array_equal(x.frames, y.frames) and np.array_equal(x.action, y.action)
+            np.testing.assert_allclose(x.reward, y.reward, rtol=1e-6, atol=1e-6)
+            assert np.array_equal(x.done, y.done)
+            assert np.array_equal(x.h0, y.h0) and np.array_equal(x.c0, y.c0)      # the state before the sequence's first frame
+    assert emitted > 100 and (short > 3 or a.keep + n + 1 >= a.total)
+    assert needed < 0.45 * 400 * E                                   # states are asked for at sequence starts only

@@ -59,7 +59,7 @@ def test_hip_learner_apex_end_to_end(tmp_path, run_id):
                       actor_param_period=10, fit_timing=5)
     exp, par = connect("inproc", run_id, create=True)
     learner = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=256, device="cuda", publish_interval=0.0)
-    v0 = learner.publish()
+    v0 = learner.publish(wait=True)
     env = envs.make_vec("SyntheticCatch-v0", 8, seed=0)
     net = DuelingDQN(4)
     actor = Actor(1, env, net, cfg, exp, par, None, 2, torch.device("cuda"), seed=0,
@@ -71,7 +71,9 @@ def test_hip_learner_apex_end_to_end(tmp_path, run_id):
     assert n == 11 and len(learner.replay) > 64 and learner.ingested >= 64
     st = learner.engine.stats()
     assert st["step"] == 11 + 2 and np.isfinite(st["loss"])            # +2 warm-up steps of the graph capture
+    learner.publish(wait=True)
     assert par.version() > v0
+    learner.close()
     files = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_*.pth")) if "aux" not in p)
     assert files == ["model_0.pth", "model_10.pth", "model_5.pth"]
     ref = DuelingDQN(4)
@@ -97,7 +99,7 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     cfg.burn_in, cfg.seq_len, cfg.overlap, cfg.nstep = 4, 8, 4, 2
     exp, par = connect("inproc", run_id, create=True)
     learner = HipLearner("r2d2", 4, cfg, exp, par, None, replay_size=64, device="cuda", publish_interval=0.0)
-    learner.publish()
+    learner.publish(wait=True)
     env = envs.make_vec("SyntheticCatch-v0", 4, seed=0)
     actor = Actor(1, env, DuelingLSTMDQN(4, 4, 4, 2), cfg, exp, par, None, 2, torch.device("cpu"),
                   target_net=DuelingLSTMDQN(4, 4, 4, 2), seed=0)
@@ -105,6 +107,7 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     actor.run(max_steps=60)
     n = learner.optimize_loop(max_steps=6, save_model_dir=str(tmp_path), warmup_timeout=60)
     assert n == 6 and np.isfinite(learner.engine.stats()["loss"])
+    learner.close()
     sd = torch.load(tmp_path / "model_4.pth", weights_only=True)
     m = DuelingLSTMDQN(4, 8, 4, 2)
     m.load_state_dict(sd)
