@@ -15,6 +15,7 @@ from __future__ import annotations
 import os
 import threading
 import time
+from collections import deque
 from typing import Optional
 
 import torch
@@ -116,6 +117,7 @@ class HipLearner:
         self.step = 0
         self._last_pub = 0.0
         self.ingested = 0
+        self.max_ahead = int(os.environ.get("DRL_LEARNER_MAX_AHEAD", "3"))     # learner steps queued ahead of the GPU
         self.pipe = None
         self._pub = None
         if self.device.type == "cuda" and os.environ.get("DRL_ASYNC_INGEST", "1") != "0":
@@ -227,6 +229,7 @@ class HipLearner:
             self.dist.barrier()
         end = None if max_steps is None else self.step + max_steps
         t_last, n_last, i_last = time.time(), self.step, self.ingested
+        inflight = deque()
         while end is None or self.step < end:
             if stop_event is not None and stop_event.is_set():
                 break
@@ -236,6 +239,14 @@ class HipLearner:
                 self.ingest()
             with ph("learner/step"):
                 self.engine.step()
+                # bound the host's run-ahead: launches are asynchronous, and a loop that queues hundreds of graph replays
+                # ahead of the GPU makes everything ordered behind "now" on the learner stream (the ingest DMA's start
+                # event, a parameter snapshot, a stop request) wait for the whole queue
+                ev = torch.cuda.Event()
+                ev.record()
+                inflight.append(ev)
+                if len(inflight) > self.max_ahead:
+                    inflight.popleft().synchronize()
             if t % cfg.publish_period == 0 and time.time() - self._last_pub >= self.publish_interval:
                 with ph("learner/publish"):
                     self.publish()
