@@ -46,9 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the R2D2 / actor / strong-scaling side measurements")
     ap.add_argument("--r2d2-steps", type=int, default=20)
     ap.add_argument("--actor-envs", type=int, default=4096)
-    ap.add_argument("--system", action="store_true",
-                    help="also run actors + learner concurrently (scripts/system_bench.py) and report the sustained rates")
-    ap.add_argument("--system-seconds", type=float, default=10.0)
+    ap.add_argument("--no-system", action="store_true",
+                    help="skip the concurrent actors + ring + ingest + learner measurement (scripts/system_bench.py; N = 1 only)")
+    ap.add_argument("--system-seconds", type=float, default=6.0)
     ap.add_argument("--check-ranks", action="store_true",
                     help="only bring up the process group (gloo without a GPU), count the ranks and print the line: "
                          "checks the self-launch path on any box")
@@ -308,14 +308,14 @@ def run_rank(args) -> int:
     rank, world = dist.rank, W
     dist.close()
 
-    if args.system and rank == 0 and world == 1:
+    if not args.no_system and not args.no_extra and rank == 0 and world == 1:
         # whole system, concurrently: K actor processes x E envs -> shm ring -> ingest thread -> HIP learner, both
         # algorithms (a child process per run, started after this process has released the GPU memory it held)
         torch.cuda.empty_cache()
         for algo in ("ape_x", "r2d2"):
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "system_bench.py"), "--algorithm", algo,
-                                    "--seconds", str(args.system_seconds)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                                    "--seconds", str(args.system_seconds)], capture_output=True, text=True, timeout=240, cwd=ROOT)
                 last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 extra["system_" + algo] = json.loads(last[-1]) if last else {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:  # noqa: BLE001
