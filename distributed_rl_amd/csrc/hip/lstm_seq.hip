@@ -35,7 +35,10 @@ struct LstmSeqNet {
 #ifndef DRL_LSTM_B128_LOADS
 #define DRL_LSTM_B128_LOADS 1
 #endif
-#define SPIN_LIMIT (1 << 17)
+// bound of every inter-workgroup poll (iterations of load + s_sleep); a device global so that a test can shrink it and
+// drive the give-up path for real (drl_lstm_set_spin_limit)
+__device__ int g_spin_limit = 1 << 17;
+#define SPIN_LIMIT g_spin_limit
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned long long u64_t;
 
@@ -456,4 +459,8 @@ DRL_API int drl_lstm_bptt(const void* dhs, const void* gates, const float* cs, v
     (void)once;
     kern<<<512 / 16, 256, LDS, s>>>(a, k_hi, steps, M, first, carry, err);
     return (int)hipGetLastError();
+}
+
+DRL_API int drl_lstm_set_spin_limit(int n) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spin_limit), &n, sizeof(int));
 }

@@ -11,8 +11,19 @@
 
 #define NPART 1024
 
-__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+// Up to four device words that turn non-zero when a bounded in-kernel wait of this step gave up (persistent LSTM / BPTT
+// hand-offs, the direct xGMI all-reduce): block 0 folds them into the STICKY fault word the update kernel checks.
+struct Guards { const int* g[4]; };
+
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ g, long long n, float* __restrict__ partial,
+                                                      Guards gd, int* __restrict__ fault) {
     __shared__ float red[32];
+    if (fault && blockIdx.x == 0 && threadIdx.x == 0) {
+        int f = *fault;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (gd.g[k] && *gd.g[k]) f |= 1 << k;
+        *fault = f;
+    }
     float acc = 0.f;
     const long long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
                                                  float* __restrict__ m2, bf16_t* __restrict__ p_bf16, long long n,
                                                  const float* __restrict__ partial, int n_partial, float grad_scale,
                                                  float max_norm, float lr, float a1, float a2, float eps, StepState* st,
-                                                 int zero_grad, int n_opt, CopyExtra cp) {
+                                                 int zero_grad, int n_opt, CopyExtra cp, const int* __restrict__ fault) {
     __shared__ float red[32];
     // optional extra block in front of the update blocks: hands the pre-drawn batch of the next step over (copies)
     const int n_smp = (int)gridDim.x - n_opt;
@@ -66,6 +77,17 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
         return;
     }
     const int ob = (int)blockIdx.x - n_smp;          // index among the update blocks
+    if (fault && *fault) {
+        // a wait inside this step timed out: its gradients are garbage. Discard the step - parameters, moments and the
+        // bf16 shadow stay as they are - but still hand the next step a zeroed gradient buffer. The word is sticky: every
+        // later step is discarded too until the host (which sees a pinned mirror of it) raises.
+        if (zero_grad) {
+            float4* g4z = reinterpret_cast<float4*>(g);
+            for (long long i = (long long)ob * blockDim.x + threadIdx.x; i < (n >> 2); i += (long long)n_opt * blockDim.x)
+                g4z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     float norm;
     const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm) * grad_scale;
     if (ob == 0 && threadIdx.x == 0 && st) st->grad_norm = norm;
@@ -131,10 +153,12 @@ static int grid_for(long long n) {
     return (int)b;
 }
 
-DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART floats */, int* n_partial_out, hipStream_t s) {
+DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART floats */, int* n_partial_out,
+                           const int* g0, const int* g1, const int* g2, const int* g3, int* fault, hipStream_t s) {
     if (n <= 0 || (n & 3)) return -1;       // flat buffers are padded to 64 elements
     int grid = grid_for(n);
-    k_sumsq_partial<<<grid, 256, 0, s>>>(g, n, partial);
+    Guards gd = {{g0, g1, g2, g3}};
+    k_sumsq_partial<<<grid, 256, 0, s>>>(g, n, partial, gd, fault);
     if (n_partial_out) *n_partial_out = grid;
     return (int)hipGetLastError();
 }
@@ -142,7 +166,7 @@ DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART 
 // copies (optional, host pointer to a CopyExtra): done by one extra block of this launch.
 DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long long n, const float* partial,
                              int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
-                             int zero_grad, const void* copies, hipStream_t s) {
+                             int zero_grad, const void* copies, const int* fault, hipStream_t s) {
     if (n <= 0 || (n & 3)) return -1;
     CopyExtra cp;
     cp.n = 0;
@@ -153,19 +177,19 @@ DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long l
     }
     const int no = grid_for(n), ns = cp.n > 0 ? 1 : 0;
     k_opt_step<0><<<no + ns, 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
-                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp);
+                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp, fault);
     return (int)hipGetLastError();
 }
 
 DRL_API int drl_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, const float* partial,
                           int n_partial, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
-                          void* st, int zero_grad, hipStream_t s) {
+                          void* st, int zero_grad, const int* fault, hipStream_t s) {
     if (n <= 0 || (n & 3) || !st) return -1;
     CopyExtra cp;
     cp.n = 0;
     const int no = grid_for(n);
     k_opt_step<1><<<no, 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
-                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp);
+                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp, fault);
     return (int)hipGetLastError();
 }
 

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void k_fix_level(TreeDesc tr, int level, const
 // dependency, duplicates resolve to the entry with the highest batch position (deterministic), all waves of a node
 // write identical values.
 __global__ __launch_bounds__(256) void k_update_l01(TreeDesc tr, const int* __restrict__ idx, const float* __restrict__ val,
-                                                   int n, const int* __restrict__ gen, const int* __restrict__ gen_expected) {
+                                                   int n, const int* __restrict__ gen, const int* __restrict__ gen_expected,
+                                                   const int* __restrict__ fault) {
+    if (fault && *fault) return;          // a discarded step (optim.hip): its priorities come from garbage Q values
     tree_update_l01_block(tr, idx, val, n, gen, gen_expected, blockIdx.x);
 }
 
@@ -144,10 +146,11 @@ static void rebuild_upper(const TreeDesc& d, void* st_end, hipStream_t s) {
 
 // set leaves + recompute all ancestor levels
 DRL_API int drl_sumtree_update(float* base, int n_levels, const long long* off, long long cap, const int* idx,
-                               const float* val, int n, const int* gen, const int* gen_expected, void* st_end, hipStream_t s) {
+                               const float* val, int n, const int* gen, const int* gen_expected, void* st_end,
+                               const int* fault, hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || n <= 0) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
-    k_update_l01<<<(n + 3) / 4, 256, 0, s>>>(d, idx, val, n, gen, gen_expected);
+    k_update_l01<<<(n + 3) / 4, 256, 0, s>>>(d, idx, val, n, gen, gen_expected, fault);
     rebuild_upper(d, st_end, s);          // levels >= 2 (+ optional fused step_end)
     return (int)hipGetLastError();
 }

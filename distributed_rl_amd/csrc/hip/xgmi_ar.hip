@@ -192,6 +192,9 @@ DRL_API int drl_xar_all_reduce(void* ctx, long long off, long long n, int channe
 }
 
 // 0 = fine; 1..3 = a poll of barrier 0..2 timed out at least once since the last call (synchronises the device)
+// device address of the timeout word (the optimizer launch reads it as a guard: optim.hip)
+DRL_API void* drl_xar_err_ptr(void* ctx) { return ctx ? (void*)((XarCtx*)ctx)->err : nullptr; }
+
 DRL_API int drl_xar_error(void* ctx) {
     XarCtx* c = (XarCtx*)ctx;
     int e = 0;

@@ -27,6 +27,7 @@ from ..models import DuelingDQN
 from ..models.packing import ParamPack, apex_layout
 from ..ops import hip as H
 from ..replay.device_per import DevicePER
+from .guard import StepGuard
 from .shard import ShardedIS
 from .streams import ForkJoin, capture_graph
 
@@ -137,6 +138,10 @@ class ApexEngine(ShardedIS):
         self.overlap = self.fj.enabled
         self._graphs = None
         self.steps_done = 0
+        # a timed-out poll of the direct xGMI all-reduce must not reach the parameters (engine/guard.py)
+        self.guard = StepGuard(dev)
+        if getattr(dist, "xgmi", None) is not None:
+            self.guard.add("direct xGMI all-reduce", dist.xgmi.err_ptr())
 
     # ---- pieces -------------------------------------------------------------------------------------
     def sync_target(self) -> None:
@@ -238,10 +243,11 @@ class ApexEngine(ShardedIS):
 
     def _optimize(self) -> None:
         cfg = self.cfg
-        H.grad_sumsq(self.G.flat, self.partial)
+        H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
                        1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
-                       copies=self.replay.handover_extra() if self.presample else None)
+                       copies=self.replay.handover_extra() if self.presample else None, fault=self.guard.fault)
+        self.guard.mirror()
         self._primed = self.presample
         if not self.fused_bwd:                                      # fused: done inside the conv backward launches
             self.replay.update(self.new_prio, end_state=self.st)    # step_end fused into the tree rebuild
@@ -324,6 +330,7 @@ class ApexEngine(ShardedIS):
         self.steps_done += 2
 
     def step(self) -> None:
+        self.guard.check()                               # raises once a discarded step has shown up in the pinned mirror
         self._maybe_refresh_shard()                      # outside the graph: the replay below reads the device scalar
         if self.use_graph:
             if self._graphs is None:
@@ -345,6 +352,8 @@ class ApexEngine(ShardedIS):
 
     # ---- host-visible state ---------------------------------------------------------------------------
     def stats(self) -> dict:
+        torch.cuda.synchronize(self.device)
+        self.guard.check()
         if getattr(self.dist, "xgmi", None) is not None:
             self.dist.check_health()                     # a timed-out poll of the direct all-reduce must not go unnoticed
         return H.read_step_state(self.st)

@@ -30,6 +30,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
+from .guard import StepGuard
 from .shard import ShardedIS
 from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
@@ -245,6 +246,15 @@ class R2D2Engine(ShardedIS):
         self.persistent_lstm = H.lstm_seq_supported(B, Hd) and os.environ.get("DRL_PERSISTENT_LSTM", "1") != "0"
         self._graphs = None
         self.steps_done = 0
+        # bounded inter-workgroup / inter-GPU waits of this step: when one gives up the step is discarded (engine/guard.py)
+        self.guard = StepGuard(dev)
+        if self.persistent_lstm:
+            self.guard.add("persistent LSTM (online)", self.on.err)
+            self.guard.add("persistent LSTM (target)", self.tg.err)
+        if self.persistent_bptt:
+            self.guard.add("persistent BPTT", self.bptt_err)
+        if getattr(dist, "xgmi", None) is not None:
+            self.guard.add("direct xGMI all-reduce", dist.xgmi.err_ptr())
 
     def sync_target(self) -> None:
         self.Tg.flat.copy_(self.P.flat)
@@ -444,11 +454,13 @@ class R2D2Engine(ShardedIS):
 
     def _optimize(self) -> None:
         cfg = self.cfg
-        H.grad_sumsq(self.G.flat, self.partial)
+        H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
         H.adam_step(self.P.flat, self.G.flat, self.M1.flat, self.M2.flat, self.Pb.flat, self.partial, self.n_partial,
                     1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, self.st,
-                    zero_grad=True)
-        self.replay.update(self.new_prio, end_state=self.st)        # step_end fused into the tree rebuild
+                    zero_grad=True, fault=self.guard.fault)
+        # step_end fused into the tree rebuild; a discarded step writes no priorities (they come from garbage Q values)
+        self.replay.update(self.new_prio, end_state=self.st, fault=self.guard.fault)
+        self.guard.mirror()
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
@@ -487,6 +499,7 @@ class R2D2Engine(ShardedIS):
         self.steps_done += 1
 
     def step(self) -> None:
+        self.guard.check()                               # raises once a discarded step has shown up in the pinned mirror
         self._maybe_refresh_shard()                      # outside the graph: the replay below reads the device scalar
         if self.use_graph:
             if self._graphs is None:
@@ -507,6 +520,7 @@ class R2D2Engine(ShardedIS):
         if getattr(self.dist, "xgmi", None) is not None:
             self.dist.check_health()
         st = H.read_step_state(self.st)
+        self.guard.check()
         if self.persistent_bptt and int(self.bptt_err[0].item()):
             raise RuntimeError("persistent BPTT kernel: an inter-workgroup wait timed out (results invalid); "
                                "set DRL_PERSISTENT_BPTT=0 to use per-step launches")

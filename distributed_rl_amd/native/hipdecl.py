@@ -9,7 +9,7 @@ SIGS = {
     "drl_step_begin": [P, P, P],
     "drl_step_end": [P, P],
     "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P, F, P],
-    "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P],
+    "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P, P],
     "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P, L, P],
     "drl_gather_rows": [P, P, P, I, I, P],
     "drl_gather_f32": [P, P, P, I, I, P],
@@ -20,9 +20,9 @@ SIGS = {
     "drl_is_weights": [P, I, P, F, P, P],
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
-    "drl_grad_sumsq": [P, L, P, POINTER(c_int), P],
-    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P],
-    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P],
+    "drl_grad_sumsq": [P, L, P, POINTER(c_int), P, P, P, P, P, P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P, P],
+    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P, P],
     "drl_cast_bf16": [P, P, L, P],
     # head.hip
     "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],
@@ -65,6 +65,7 @@ SIGS = {
     "drl_xar_open": [P, I, P, I],
     "drl_xar_all_reduce": [P, L, L, I, P],
     "drl_xar_error": [P],
+    "drl_lstm_set_spin_limit": [I],
     "drl_xar_set_timeout": [P, c_double],
     "drl_xar_destroy": [P],
 }
@@ -80,3 +81,5 @@ def declare(lib) -> None:
     if hasattr(lib, "drl_xar_data_ptr"):
         lib.drl_xar_data_ptr.restype = c_void_p
         lib.drl_xar_data_ptr.argtypes = [c_void_p]
+        lib.drl_xar_err_ptr.restype = c_void_p
+        lib.drl_xar_err_ptr.argtypes = [c_void_p]

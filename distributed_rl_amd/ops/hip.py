@@ -118,13 +118,14 @@ def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: 
 
 def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
                    gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
-                   end_state: Optional[torch.Tensor] = None) -> None:
+                   end_state: Optional[torch.Tensor] = None, fault: Optional[torch.Tensor] = None) -> None:
     """Two launches for any depth: leaves + level 1 (one wave per index), then every level >= 2 rebuilt from level 1.
-    ``end_state`` fuses step_end (step += 1) into the second launch."""
+    ``end_state`` fuses step_end (step += 1) into the second launch. ``fault`` (int32 device word, see grad_sumsq):
+    non-zero = the priorities of a discarded step are not written."""
     _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
     assert idx.numel() == val.numel()
     _ck(native.hip().drl_sumtree_update(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(idx), _p(val), idx.numel(),
-                                        _p(gen), _p(gen_expected), _p(end_state), _s()), "sumtree_update")
+                                        _p(gen), _p(gen_expected), _p(end_state), _p(fault), _s()), "sumtree_update")
 
 
 def sumtree_ingest(tree: torch.Tensor, lay: TreeLayout, start: int, prio: Optional[torch.Tensor], gen: Optional[torch.Tensor],
@@ -198,27 +199,48 @@ def n_partials(n: int) -> int:
     return max(1, min(1024, (n // 4 + 255) // 256))
 
 
-def grad_sumsq(g: torch.Tensor, partial: torch.Tensor) -> int:
+def _gp(x):
+    """Guard word: an int32 device tensor, a raw device address, or None."""
+    if x is None:
+        return None
+    return ctypes.c_void_p(x) if isinstance(x, int) else _p(x)
+
+
+def grad_sumsq(g: torch.Tensor, partial: torch.Tensor, guards=(), fault: Optional[torch.Tensor] = None) -> int:
+    """Partial sums of squares of the flat gradient. ``guards``: up to four int32 device words (tensors or raw addresses)
+    that are non-zero when a bounded in-kernel wait of this step gave up; they are folded into the sticky ``fault`` word
+    the update kernel (``rmsprop_step`` / ``adam_step`` with the same ``fault``) checks before it touches a parameter."""
     _chk(g, torch.float32, "g"); _chk(partial, torch.float32, "partial")
-    assert partial.numel() >= 1024
+    assert partial.numel() >= 1024 and len(guards) <= 4
+    if fault is not None:
+        _chk(fault, torch.int32, "fault")
+    gs = [_gp(x) for x in guards] + [None] * (4 - len(guards))
     n = ctypes.c_int()
-    _ck(native.hip().drl_grad_sumsq(_p(g), g.numel(), _p(partial), ctypes.byref(n), _s()), "grad_sumsq")
+    _ck(native.hip().drl_grad_sumsq(_p(g), g.numel(), _p(partial), ctypes.byref(n), gs[0], gs[1], gs[2], gs[3], _p(fault), _s()),
+        "grad_sumsq")
     return n.value
 
 
+def lstm_set_spin_limit(n: int) -> None:
+    """Bound (poll iterations) of the inter-workgroup waits of the persistent LSTM / BPTT kernels; default 1 << 17. Tests
+    shrink it to drive the give-up path."""
+    _ck(native.hip().drl_lstm_set_spin_limit(int(n)), "lstm_set_spin_limit")
+
+
 def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st,
-                 zero_grad: bool = False, copies: Optional["CopyExtra"] = None) -> None:
+                 zero_grad: bool = False, copies: Optional["CopyExtra"] = None, fault: Optional[torch.Tensor] = None) -> None:
     """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch). ``copies``
-    (see copy_extra) are done by one extra block of the same launch."""
+    (see copy_extra) are done by one extra block of the same launch. ``fault`` (see grad_sumsq): non-zero = the step is
+    discarded (nothing but the gradient zeroing and the copies happens)."""
     _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
                                       max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0,
-                                      ctypes.byref(copies) if copies is not None else None, _s()), "rmsprop_step")
+                                      ctypes.byref(copies) if copies is not None else None, _p(fault), _s()), "rmsprop_step")
 
 
 def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st,
-              zero_grad: bool = False) -> None:
+              zero_grad: bool = False, fault: Optional[torch.Tensor] = None) -> None:
     _ck(native.hip().drl_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
-                                   max_norm, lr, b1, b2, eps, _p(st), 1 if zero_grad else 0, _s()), "adam_step")
+                                   max_norm, lr, b1, b2, eps, _p(st), 1 if zero_grad else 0, _p(fault), _s()), "adam_step")
 
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:

@@ -114,6 +114,10 @@ class XgmiAllReduce:
         """Bound of every flag poll inside the kernel (launches issued after this call)."""
         self._ck(self.lib.drl_xar_set_timeout(self._ctx, float(seconds)), "set_timeout")
 
+    def err_ptr(self) -> int:
+        """Device address of the timeout word (a guard of the optimizer launch, ops.hip.grad_sumsq)."""
+        return int(self.lib.drl_xar_err_ptr(self._ctx) or 0)
+
     def error(self) -> int:
         """0 = fine; otherwise the barrier (1..3) whose poll timed out. Synchronises the device."""
         with torch.cuda.device(self.device):

@@ -130,8 +130,8 @@ class DeviceSequenceReplay:
                          begin_n_items=(n_is if n_is is not None else self.n_items) if begin else None)
         H.seq_offsets(self.idx, self.T, self.frame_bytes, self.frame_off)
 
-    def update(self, new_prio: torch.Tensor, end_state=None) -> None:
-        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
+    def update(self, new_prio: torch.Tensor, end_state=None, fault=None) -> None:
+        H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state, fault=fault)
 
     def remove_to_fit(self) -> int:
         return 0

@@ -1,0 +1,130 @@
+"""Production-shape correctness and safety of the gfx950 learner engines.
+
+* The engines at the shapes the benchmarks run (Ape-X B = 512; R2D2 B = 64, burn-in 40, sequence 80, n = 5, through the
+  persistent forward recurrence and the persistent BPTT) against plain PyTorch fp32 autograd of the same batch: every
+  gradient tensor's cosine similarity and relative error (printed; bounds asserted).
+* A step whose bounded in-kernel wait timed out is DISCARDED: parameters, optimizer moments and replay priorities stay
+  untouched and the next ``step()`` raises - driven for real by shrinking the spin bound of the persistent kernels.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from distributed_rl_amd.models import DuelingDQN, DuelingLSTMDQN  # noqa: E402
+from distributed_rl_amd.ops import hip as H  # noqa: E402
+from distributed_rl_amd.ops import oracle  # noqa: E402
+
+from test_engine_gpu import _r2d2_setup, _setup  # noqa: E402
+
+
+def _cmp(grads, model):
+    rows = {}
+    for name, p in model.named_parameters():
+        g, ref = grads[name].double().flatten().cpu(), p.grad.double().flatten().cpu()
+        cos = float(torch.dot(g, ref) / (g.norm() * ref.norm() + 1e-30))
+        rows[name] = (cos, float((g - ref).norm() / (ref.norm() + 1e-30)))
+    return rows
+
+
+def test_apex_engine_batch_512_vs_fp32_autograd():
+    model, cfg, rep, eng = _setup(B=512, cap=4000, A=6)
+    target = DuelingDQN(eng.A).cuda()
+    model.cuda()
+    target.load_state_dict(model.state_dict())
+    eng._forward_backward()
+    torch.cuda.synchronize()
+    B = 512
+    idx = rep.idx.long()
+    s = rep.frames[:rep.capacity][idx].view(B, 84, 84, 4)
+    s2 = rep.frames[rep.capacity:][idx].view(B, 84, 84, 4)
+    st = eng.stats()
+    w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"]).cuda()
+    torch.backends.cudnn.allow_tf32 = False
+    model.zero_grad()
+    td = model.td_batch(target, s, rep.act[idx].long(), rep.rew[idx], s2, rep.done[idx], w, cfg.per_alpha, cfg.gamma_n)
+    td.loss.backward()
+    assert st["loss"] == pytest.approx(float(td.loss), rel=2e-2, abs=1e-3)
+    pr, pe = eng.new_prio.double().cpu(), td.prio.double().cpu()
+    assert float(torch.dot(pr, pe) / (pr.norm() * pe.norm())) > 0.999
+    rows = _cmp(eng.G.state_dict(), model)
+    print({k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
+    assert all(c >= 0.999 for c, _ in rows.values()), rows
+    assert all(e <= 0.04 for _, e in rows.values()), rows            # was 0.06 at B = 64 (tests/test_engine_gpu.py)
+
+
+@pytest.mark.parametrize("B", [64])
+def test_r2d2_engine_production_shape_vs_fp32_autograd(B):
+    model, cfg, rep, eng = _r2d2_setup(B=B, burn=40, seq=80, n=5, A=4, cap=2 * B, seed=1)
+    assert eng.persistent_lstm and eng.persistent_bptt              # B % 16 == 0: the persistent kernels are on the path
+    target = DuelingLSTMDQN(eng.A, B, cfg.burn_in, cfg.nstep)
+    target.load_state_dict(model.state_dict())
+    model.to("cuda")
+    target.to("cuda")
+    eng._forward_backward()
+    torch.cuda.synchronize()
+    T = cfg.total_len
+    idx = rep.idx.long()
+    frames = rep.frames.view(rep.capacity, T, 84, 84, 4)[idx].permute(1, 0, 2, 3, 4).contiguous()
+    a, r, d = rep.act[idx].t().long(), rep.rew[idx].t(), rep.done[idx].t()
+    lens = rep.length[idx].long()
+    h0, c0 = rep.h0[idx], rep.c0[idx]
+    st = eng.stats()                                                  # also raises if a persistent kernel timed out
+    w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"]).cuda()
+    model.zero_grad()
+    td = model.sequence_td(target, frames, a, r, d, lens, h0, c0, w, cfg.eta, cfg.gamma_n, cfg.rescale_eps)
+    td.loss.backward()
+    with torch.no_grad():
+        q_ref, _ = model.unroll(frames, h0, c0, grad_from=T)
+    q = eng.on.q.view(T, B, -1)
+    print("max |dQ| over 120 recurrent steps:", float((q - q_ref).abs().max()), " |Q| max:", float(q_ref.abs().max()))
+    torch.testing.assert_close(q, q_ref, rtol=5e-2, atol=5e-2)
+    assert st["loss"] == pytest.approx(float(td.loss.detach()), rel=5e-2, abs=5e-3)
+    pr, pe = eng.new_prio.double().cpu(), td.prio.double().cpu()
+    assert float(torch.dot(pr, pe) / (pr.norm() * pe.norm())) > 0.999
+    rows = _cmp(eng.G.state_dict(), model)
+    print({k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
+    assert all(c >= 0.999 for c, _ in rows.values()), rows
+    assert all(e <= 0.06 for _, e in rows.values()), rows            # was 0.10 at B = 8, T = 12
+
+
+def test_apex_step_with_a_fired_guard_is_discarded_and_the_next_step_raises():
+    model, cfg, rep, eng = _setup(B=64)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.guard.add("injected", flag)                                   # stands for the xGMI all-reduce's timeout word
+    eng.use_graph = True
+    for _ in range(3):
+        eng.step()
+    torch.cuda.synchronize()
+    p0, sq0, pb0 = eng.P.flat.clone(), eng.SQ.flat.clone(), eng.Pb.flat.clone()
+    flag.fill_(1)                                                     # what a kernel does when its bounded poll gives up
+    eng.step()                                                        # launched: the mirror still shows a clean state
+    torch.cuda.synchronize()
+    assert torch.equal(eng.P.flat, p0) and torch.equal(eng.SQ.flat, sq0) and torch.equal(eng.Pb.flat, pb0)
+    assert float(eng.G.flat.abs().sum()) == 0.0                       # the next step still starts from zeroed gradients
+    with pytest.raises(RuntimeError, match="discarded.*injected"):
+        eng.step()
+    flag.zero_()                                                      # the fault word is sticky: clearing the source is not enough
+    with pytest.raises(RuntimeError, match="discarded"):
+        eng.stats()
+
+
+def test_r2d2_persistent_kernel_timeout_discards_the_step():
+    _, cfg, rep, eng = _r2d2_setup(B=16, burn=4, seq=8, n=2, cap=48, seed=2)
+    assert eng.persistent_lstm and eng.persistent_bptt
+    eng.use_graph = True
+    for _ in range(2):
+        eng.step()
+    eng.stats()
+    p0, m0, tree0 = eng.P.flat.clone(), eng.M1.flat.clone(), rep.tree.clone()
+    try:
+        H.lstm_set_spin_limit(0)                                      # every unsatisfied inter-workgroup poll gives up at once
+        eng.step()
+        torch.cuda.synchronize()
+    finally:
+        H.lstm_set_spin_limit(1 << 17)
+    assert int(eng.on.err[0]) or int(eng.tg.err[0]) or int(eng.bptt_err[0])   # a wait really timed out ...
+    assert torch.equal(eng.P.flat, p0) and torch.equal(eng.M1.flat, m0)      # ... no parameter / moment moved ...
+    assert torch.equal(rep.tree, tree0)                                      # ... and no priority was written
+    with pytest.raises(RuntimeError, match="discarded.*persistent"):
+        eng.step()
