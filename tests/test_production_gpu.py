@@ -18,6 +18,31 @@ from distributed_rl_amd.ops import oracle  # noqa: E402
 from test_engine_gpu import _r2d2_setup, _setup  # noqa: E402
 
 
+class _RoundBf16(torch.autograd.Function):
+    """x -> bf16(x) in the forward pass, g -> bf16(g) in the backward pass: where the kernels store an activation /
+    an activation gradient as bf16, the fp32 oracle rounds too. What is left between engine and oracle is then
+    accumulation order and the fused epilogues, not storage precision."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _emulate_bf16_storage(model, names):
+    hs = []
+    for n in names:
+        def hook(mod, inp, out):
+            if isinstance(out, tuple):                      # LSTMCell: (h, c) - the kernels keep h in bf16, c in fp32
+                return (_RoundBf16.apply(out[0]),) + tuple(out[1:])
+            return _RoundBf16.apply(out)
+        hs.append(getattr(model, n).register_forward_hook(hook))
+    return hs
+
+
 def _cmp(grads, model):
     rows = {}
     for name, p in model.named_parameters():
@@ -48,9 +73,22 @@ def test_apex_engine_batch_512_vs_fp32_autograd():
     pr, pe = eng.new_prio.double().cpu(), td.prio.double().cpu()
     assert float(torch.dot(pr, pe) / (pr.norm() * pe.norm())) > 0.999
     rows = _cmp(eng.G.state_dict(), model)
-    print({k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
-    assert all(c >= 0.999 for c, _ in rows.values()), rows
-    assert all(e <= 0.04 for _, e in rows.values()), rows            # was 0.06 at B = 64 (tests/test_engine_gpu.py)
+    print("vs fp32:", {k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
+    # the same oracle with bf16 STORAGE of the activations the kernels store in bf16 (compute stays fp32)
+    for m in (model, target):
+        _emulate_bf16_storage(m, ["conv1", "conv2", "conv3", "adv1", "val1"])
+    model.zero_grad()
+    td2 = model.td_batch(target, s, rep.act[idx].long(), rep.rew[idx], s2, rep.done[idx], w, cfg.per_alpha, cfg.gamma_n)
+    td2.loss.backward()
+    rows2 = _cmp(eng.G.state_dict(), model)
+    print("vs fp32 with bf16 storage:", {k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows2.items()})
+    # measured (MI355X, r2): vs fp32 cos >= 0.99856, rel. error <= 5.4 % - all of it bf16 STORAGE of activations and
+    # activation gradients (uniform-noise frames put many pre-activations next to the ReLU threshold): with the same
+    # storage rounding in the oracle cos >= 0.99990 and the error <= 1.4 %
+    assert all(c >= 0.998 for c, _ in rows.values()), rows
+    assert all(e <= 0.06 for _, e in rows.values()), rows
+    assert all(c >= 0.9998 for c, _ in rows2.values()), rows2
+    assert all(e <= 0.02 for _, e in rows2.values()), rows2
 
 
 @pytest.mark.parametrize("B", [64])
@@ -83,9 +121,18 @@ def test_r2d2_engine_production_shape_vs_fp32_autograd(B):
     pr, pe = eng.new_prio.double().cpu(), td.prio.double().cpu()
     assert float(torch.dot(pr, pe) / (pr.norm() * pe.norm())) > 0.999
     rows = _cmp(eng.G.state_dict(), model)
-    print({k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
+    print("vs fp32:", {k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows.items()})
+    for m in (model, target):
+        _emulate_bf16_storage(m, ["conv1", "conv2", "conv3", "lstm", "adv1", "val1"])
+    model.zero_grad()
+    td2 = model.sequence_td(target, frames, a, r, d, lens, h0, c0, w, cfg.eta, cfg.gamma_n, cfg.rescale_eps)
+    td2.loss.backward()
+    rows2 = _cmp(eng.G.state_dict(), model)
+    print("vs fp32 with bf16 storage:", {k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows2.items()})
+    # measured (MI355X, r2): cos >= 0.99952 / rel. error <= 3.1 % vs fp32; cos >= 0.99970 with bf16 storage emulated
     assert all(c >= 0.999 for c, _ in rows.values()), rows
-    assert all(e <= 0.06 for _, e in rows.values()), rows            # was 0.10 at B = 8, T = 12
+    assert all(e <= 0.05 for _, e in rows.values()), rows            # was 0.10 at B = 8, T = 12
+    assert all(c >= 0.999 for c, _ in rows2.values()), rows2
 
 
 def test_apex_step_with_a_fired_guard_is_discarded_and_the_next_step_raises():
