@@ -66,6 +66,8 @@ SIGS = {
     "drl_xar_all_reduce": [P, L, L, I, P],
     "drl_xar_error": [P],
     "drl_lstm_set_spin_limit": [I],
+    # gemm_big.hip
+    "drl_gemm_big": [I, I, P, L, P, L, I, I, I, P, L, P, P, L, I, P, P, P, P, P, P],
     "drl_xar_set_timeout": [P, c_double],
     "drl_xar_destroy": [P],
 }

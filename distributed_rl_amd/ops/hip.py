@@ -284,6 +284,61 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
                               scale, flags, splits, _s()), "gemm")
 
 
+# ---- large-tile GEMM (csrc/hip/gemm_big.hip): the big dense products of the R2D2 step -------------------------------
+# tile ids: 0 = 256x256 (2 LDS stages) | 1 = 256x128 (3) | 2 = 128x256 (3) | 3 = 128x128 (4) | 4 = 256x128 (2) | 5 = 128x128 (3)
+BIG_TILES = {0: (256, 256), 1: (256, 128), 2: (128, 256), 3: (128, 128), 4: (256, 128), 5: (128, 128)}
+BIG_GEMM = os.environ.get("DRL_BIG_GEMM", "1") != "0"
+BIG_GEMM_MIN_FLOP = 2.0e10
+
+
+def big_tile_for(M: int, N: int, nz: int = 1) -> int:
+    """Tile with the least (rounds over the 256 CUs) x (tile area) x (measured inefficiency of the smaller tiles: one
+    256 x 128 tile costs 0.64 of a 256 x 256 one, a 128 x 128 tile 0.36 - scripts/gemm_big_bench.py)."""
+    best, best_cost = 3, None
+    for t, ineff in ((0, 1.0), (1, 1.27), (2, 1.27), (3, 1.44)):
+        bm, bn = BIG_TILES[t]
+        blocks = -(-M // bm) * -(-N // bn) * nz
+        cost = -(-blocks // 256) * bm * bn * ineff
+        if best_cost is None or cost < best_cost:
+            best, best_cost = t, cost
+    return best
+
+
+def use_big_gemm(M: int, N: int, K: int) -> bool:
+    return BIG_GEMM and 2.0 * M * N * K >= BIG_GEMM_MIN_FLOP
+
+
+def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             mask: Optional[torch.Tensor] = None, tile: Optional[int] = None, second=None) -> None:
+    """c = a.b^T (NT: a [M,K], b [N,K]) | a.b (NN: a [M,K], b [K,N]) | a^T.b (TN: a [K,M], b [K,N]); a, b bf16 row-major
+    2-D (row stride = shape[1]); c fp32 or bf16 [M,N]; ``bias`` fp32 [N] added, ``mask`` bf16 [M,N]: c = 0 where mask <= 0
+    (ReLU backward) - both in the epilogue, no second pass. ``second`` = (a2, b2, c2, bias2, mask2): a second problem of the
+    same shape in the same launch (two networks fill the 256 CUs together where each alone would not)."""
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    assert a.dim() == 2 and b.dim() == 2 and c.dim() == 2
+    if mode == NT:
+        M, K = a.shape; N = b.shape[0]; assert b.shape[1] == K
+    elif mode == NN:
+        M, K = a.shape; N = b.shape[1]; assert b.shape[0] == K
+    else:
+        K, M = a.shape; N = b.shape[1]; assert b.shape[0] == K
+    assert tuple(c.shape) == (M, N) and c.dtype in (torch.float32, torch.bfloat16) and c.is_contiguous()
+    if bias is not None:
+        _chk(bias, torch.float32, "bias"); assert bias.numel() == N
+    if mask is not None:
+        _chk(mask, torch.bfloat16, "mask"); assert tuple(mask.shape) == (M, N)
+    a2 = b2 = c2 = bias2 = mask2 = None
+    if second is not None:
+        a2, b2, c2, bias2, mask2 = second
+        _chk(a2, torch.bfloat16, "a2"); _chk(b2, torch.bfloat16, "b2")
+        assert a2.shape == a.shape and b2.shape == b.shape and c2.shape == c.shape and c2.dtype == c.dtype and c2.is_contiguous()
+        assert (bias2 is None) == (bias is None) and (mask2 is None) == (mask is None)
+    t = big_tile_for(M, N, 2 if second is not None else 1) if tile is None else tile
+    _ck(native.hip().drl_gemm_big(mode, t, _p(a), a.shape[1], _p(b), b.shape[1], M, N, K, _p(c), N, _p(bias), _p(mask),
+                                  N if mask is not None else 0, 1 if c.dtype == torch.float32 else 0,
+                                  _p(a2), _p(b2), _p(c2), _p(bias2), _p(mask2), _s()), "gemm_big")
+
+
 # layers whose forward uses the barrier-free direct kernels (conv_direct.hip); the others run the LDS-tiled implicit
 # GEMM (gemm.hip). Measured on MI355X at 1024 frames: conv1 20.6 us direct vs 35.4 tiled; conv2 21.3 vs 17.0; conv3
 # 16.5 vs 13.4 -> only conv1 goes direct by default.
