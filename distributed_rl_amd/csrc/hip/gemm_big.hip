@@ -105,15 +105,31 @@ struct BigOperand {
         if constexpr (!TR) {
             return *reinterpret_cast<const bf16x8*>(lds + big_nrm_off<OUT>(o0 + (lane & 15), ks * 4 + (lane >> 4)));
         } else {
+            // INLINE ASM on purpose: with the __builtin_amdgcn_ds_read_tr16_b64 form hipcc (ROCm 7.2) puts an
+            // s_waitcnt vmcnt(0) in front of the first transposed read of every K-tile - it drains the LDS-DMAs of the
+            // NEXT tiles that were issued a few instructions earlier, i.e. the whole prefetch pipeline (NN / TN ran 1.4 x
+            // slower per K-tile than NT, whose ds_read_b128 gets no such wait). The asm reads are invisible to the
+            // compiler's counters: the caller waits lgkmcnt(0) and pins every fragment (big_land) before the MFMAs.
             const int g = lane >> 4, w = lane & 15, q = w >> 2, pp = w & 3;
             const int k1 = ks * 32 + 8 * g + q, k2 = k1 + 4, unit = o0 >> 4;
-            big_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) big_s16x4*)(lds + big_tr_off<OUT>(k1, unit) + pp * 8));
-            big_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) big_s16x4*)(lds + big_tr_off<OUT>(k2, unit) + pp * 8));
+            const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)lds;
+            const uint32_t a1 = base + big_tr_off<OUT>(k1, unit) + pp * 8, a2 = base + big_tr_off<OUT>(k2, unit) + pp * 8;
+            big_s16x4 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a2));
             bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             return f;
         }
     }
 };
+
+// after asm LDS reads: one wait for everything in flight, then every fragment is made opaque at this point so that no
+// MFMA consuming it can be scheduled above the wait (guide 5.7: form (ii) / rule 18)
+template <int N>
+__device__ __forceinline__ void big_land(bf16x8 (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
+}
 
 __device__ __forceinline__ void big_tile_remap(int& bx, int& by, int gx, int gy) {
     if (gx < 2 || gy < 2) return;
@@ -169,6 +185,12 @@ __global__ __launch_bounds__(BIG_T) void k_gemm_big(BigOperand<BM, A_TR> A, BigO
             for (int j = 0; j < TN; ++j) bfr[j] = OB::frag(Bs, wn * (BN / WN) + j * 16, ks, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = OA::frag(As, wm * (BM / WM) + i * 16, ks, lane);
+            if constexpr (A_TR || B_TR) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                big_land<TN>(bfr);
+                big_land<TM>(af);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)

@@ -77,10 +77,12 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     if t0 == 0:
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
     xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
-    if H.use_lib_gemm(n, 4 * Hd, 3136):        # big plain product: hipBLASLt (see ops.hip.lib_gemm), bias as a second pass
+    if H.use_lib_gemm(n, 4 * Hd, 3136):        # A/B switch DRL_LIB_GEMM=1: hipBLASLt (ops.hip.lib_gemm), bias as a second pass
         H.lib_gemm(H.NT, a3, wb.view("lstm.w_ih"), xg)
         if not defer_xg_bias(n, Hd, persistent):
             xg.add_(bsum)
+    elif H.use_big_gemm(n, 4 * Hd, 3136):      # 8-wave large-tile kernel (gemm_big.hip), bias in the epilogue
+        H.gemm_big(H.NT, a3, wb.view("lstm.w_ih"), xg, bias=bsum)
     else:
         H.gemm(H.NT, a3, wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
 
@@ -102,9 +104,16 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
                         getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1])
-    for wb, wf, buf, bsum in (net1, net2):
-        if t0 == 0:
+    if t0 == 0:
+        for wb, wf, buf, bsum in (net1, net2):
             H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
+    if not H.use_lib_gemm(n, 4 * Hd, 3136) and H.use_big_gemm(n, 4 * Hd, 3136):
+        # the input projections of BOTH networks as one launch: a forward chunk of one network alone leaves the 256 CUs
+        # half empty (72 x 64 rows = 144 tiles of 256 x 256), two of them fill the chip
+        H.gemm_big(H.NT, b1.act3[r0:r1], wb1.view("lstm.w_ih"), b1.xg.view(T * B, 4 * Hd)[r0:r1], bias=bs1,
+                   second=(b2.act3[r0:r1], wb2.view("lstm.w_ih"), b2.xg.view(T * B, 4 * Hd)[r0:r1], bs2, None))
+        return
+    for wb, wf, buf, bsum in (net1, net2):
         xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
         if H.use_lib_gemm(n, 4 * Hd, 3136):
             H.lib_gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg)
@@ -238,6 +247,11 @@ class R2D2Engine(ShardedIS):
                 # chunk leaves a shorter recurrence after the last torso (2.36 / 2.33 / 2.33 / 2.37 / 2.43 ms per step for a
                 # cut at 60 / 72 / 80 / 90 / 100 of 120)
                 cuts = [(3 * self.T) // 5]
+                # the input projections of both networks run as ONE large-tile launch per chunk (gemm_big.hip): keep each
+                # chunk within one round of 256 tiles of 256 x 256 (2 networks x rows/256 x 4H/256 tiles)
+                cap_rows = 256 * 256 // (2 * max(1, 4 * self.Hd // 256))
+                if H.BIG_GEMM and not H.LIB_GEMM and cuts[0] * self.B > cap_rows >= self.B and self.T * self.B <= 2 * cap_rows:
+                    cuts = [max(self.T - cap_rows // self.B, min(cuts[0], cap_rows // self.B))]
         self.fwd_bounds = list(zip([0] + cuts, cuts + [self.T]))
         self.fwd_chunks = len(self.fwd_bounds)
         self.world = dist.world_size if dist is not None else 1
@@ -407,6 +421,8 @@ class R2D2Engine(ShardedIS):
             G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
         if H.use_lib_gemm(4 * Hd, 3136, NB):
             H.lib_gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"))
+        elif H.use_big_gemm(4 * Hd, 3136, NB):
+            H.gemm_big(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"))
         else:
             H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
         fj.join()
@@ -424,6 +440,8 @@ class R2D2Engine(ShardedIS):
         if H.use_lib_gemm(n, 3136, 4 * Hd):
             H.lib_gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136))
             H.relu_mask(d3, a3, d3)                                 # the mask the fused epilogue would have applied
+        elif H.use_big_gemm(n, 3136, 4 * Hd):
+            H.gemm_big(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), mask=a3)      # ReLU mask in the epilogue
         else:
             H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
         if self.fused_bwd:                                          # dX + dW + db of a conv layer = one launch (k_multi)

@@ -575,7 +575,7 @@ def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
 # vendor library is 2-3x faster (measured, scripts/debug/mm_bench.py: 7680x2048x3136 NT 93 us vs 232 us, 2048x3136x5120
 # TN 102 vs 195 us, 5120x3136x2048 NN 95 vs 177 us), so those - and only those - go to hipBLASLt through torch.mm with fp32
 # accumulation and (where the consumer wants it) fp32 output. DRL_LIB_GEMM=0 keeps everything on gemm.hip.
-LIB_GEMM = os.environ.get("DRL_LIB_GEMM", "1") != "0"
+LIB_GEMM = os.environ.get("DRL_LIB_GEMM", "0") != "0"       # hipBLASLt for the big plain products: off (gemm_big.hip), A/B switch only
 LIB_GEMM_MIN_FLOP = float(os.environ.get("DRL_LIB_GEMM_MIN_FLOP", "2.0e10"))
 
 

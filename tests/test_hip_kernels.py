@@ -834,3 +834,50 @@ def test_conv1_fwd_apex_layout_matches_single_network_launches(hip):
     o1, o2 = torch.zeros_like(ref1), torch.zeros_like(ref2)
     H.conv1_fwd_apex(store, off[:B], B, off[B:], B, w1, b1, o1[:B], o1[B:], w2, b2, o2)
     assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+
+
+# ---- large-tile GEMM (csrc/hip/gemm_big.hip) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_gemm_big_matches_fp32_product(mode, tile):
+    """Every tile shape x operand orientation on sizes that are NOT multiples of the tile (edge rows / columns / k come
+    from the zero page), with the fused bias (NT) and ReLU-mask (NN) epilogues, fp32 and bf16 outputs."""
+    from distributed_rl_amd.ops import hip as H
+    torch.manual_seed(3)
+    M, N, K = 328, 456, 200
+    dev = "cuda"
+    rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1).to(torch.bfloat16)   # noqa: E731
+    if mode == "NT":
+        a, b = rnd(M, K), rnd(N, K)
+        ref = a.float() @ b.float().t()
+    elif mode == "NN":
+        a, b = rnd(M, K), rnd(K, N)
+        ref = a.float() @ b.float()
+    else:
+        a, b = rnd(K, M), rnd(K, N)
+        ref = a.float().t() @ b.float()
+    bias = torch.randn(N, device=dev) if mode == "NT" else None
+    mask = rnd(M, N) if mode == "NN" else None
+    if bias is not None:
+        ref = ref + bias
+    if mask is not None:
+        ref = ref * (mask.float() > 0)
+    c = torch.full((M, N), 7.0, dtype=torch.bfloat16 if mode == "NN" else torch.float32, device=dev)
+    H.gemm_big({"NT": H.NT, "NN": H.NN, "TN": H.TN}[mode], a, b, c, bias=bias, mask=mask, tile=tile)
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-2, atol=6e-2) if mode == "NN" else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(c.float(), ref, **tol)
+
+
+def test_gemm_big_two_problems_per_launch():
+    from distributed_rl_amd.ops import hip as H
+    torch.manual_seed(4)
+    M, N, K = 520, 384, 320
+    rnd = lambda *s: (torch.rand(*s, device="cuda") * 2 - 1).to(torch.bfloat16)   # noqa: E731
+    a, a2, b, b2 = rnd(M, K), rnd(M, K), rnd(N, K), rnd(N, K)
+    bias, bias2 = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+    c, c2 = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    H.gemm_big(H.NT, a, b, c, bias=bias, second=(a2, b2, c2, bias2, None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(c, a.float() @ b.float().t() + bias, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(c2, a2.float() @ b2.float().t() + bias2, rtol=1e-4, atol=1e-4)
