@@ -39,6 +39,8 @@ SIGS = {
     "drl_conv1_fwd_apex": [P, P, I, P, I, P, P, P, P, P, P, P, P],
     # conv_direct.hip
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
+    # conv_halo.hip
+    "drl_conv_halo_fwd": [I, P, I, P, P, P, P, I, P, P, P, I, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
     "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P, P],

@@ -350,11 +350,38 @@ CONV_FWD_DIRECT = (1,)
 CONV_FWD_TILED_VARIANT = {2: 0, 3: 1}
 
 
+# conv2 / conv3 forward through the LDS-halo kernels (conv_halo.hip: whole input frames staged in LDS once, weights in
+# registers). DRL_CONV_HALO=0 falls back to the implicit-GEMM tiles of gemm.hip (A/B switch).
+CONV_HALO = os.environ.get("DRL_CONV_HALO", "1") != "0"
+# variant 0 = two workgroups per CU, 1 = one per CU. Measured (scripts/conv_halo_bench.py, us, v0 / v1 / implicit GEMM):
+#   conv2 1024+512 frames 19.2 / 17.9 / 24.5, 2 x 3840 frames 48.7 / 54.6 / 95.0;  conv3 15.5 (v1) / 20.3, 34.2 (v1) / 62.8
+CONV_HALO_VARIANT = {2: int(os.environ.get("DRL_CONV2_HALO_VARIANT", "-1")), 3: int(os.environ.get("DRL_CONV3_HALO_VARIANT", "1"))}
+
+
+def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w2=None, b2=None, out2=None,
+                  variant: Optional[int] = None) -> None:
+    """conv2 / conv3 (+bias+ReLU) of one or two networks in one launch of the LDS-halo kernel."""
+    assert layer in (2, 3)
+    ci, co = ((20 * 20 * 32, 81 * 64) if layer == 2 else (81 * 64, 49 * 64))
+    for x, f, w, b, o in ((x1, f1, w1, b1, out1),) + (((x2, f2, w2, b2, out2),) if f2 else ()):
+        _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(b, torch.float32, "bias"); _chk(o, torch.bfloat16, "out")
+        assert x.numel() >= f * ci and o.numel() >= f * co and w.numel() == 64 * (512 if layer == 2 else 576) and b.numel() == 64
+    v = CONV_HALO_VARIANT[layer] if variant is None else variant
+    if v < 0:
+        v = 1 if f1 + f2 <= 2048 else 0
+    _ck(native.hip().drl_conv_halo_fwd(layer, _p(x1), f1, _p(w1), _p(b1), _p(out1), _p(x2) if f2 else None, f2,
+                                       _p(w2) if f2 else None, _p(b2) if f2 else None, _p(out2) if f2 else None, v, _s()),
+        "conv_halo_fwd")
+
+
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
              frame_off: Optional[torch.Tensor] = None, relu: bool = True, direct: Optional[bool] = None,
              variant: int = 0) -> None:
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
     _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
+    if layer != 1 and CONV_HALO and relu and direct is None:
+        conv_halo_fwd(layer, x, frames, w, bias, out)
+        return
     if ((layer in CONV_FWD_DIRECT) if direct is None else direct) and relu:
         _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
             "conv_fwd_direct")
@@ -375,6 +402,9 @@ def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, ou
                                             _p(b2), _p(out2), _s()), "conv1_fwd_dual")
         return
     _chk(x1, torch.bfloat16, "x1"); _chk(x2, torch.bfloat16, "x2")
+    if CONV_HALO:
+        conv_halo_fwd(layer, x1, f1, w1, b1, out1, x2, f2, w2, b2, out2)
+        return
     _ck(native.hip().drl_conv_fwd_dual(layer, _p(x1), f1, _p(w1), _p(b1), _p(out1), _p(x2), f2, _p(w2), _p(b2), _p(out2), _s()),
         "conv_fwd_dual")
 

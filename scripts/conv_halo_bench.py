@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""conv2 / conv3 forward: LDS-halo kernels (conv_halo.hip) against the implicit-GEMM tiles of gemm.hip, at the learners'
+launch shapes (Ape-X: online 1024 + target 512 frames per launch; R2D2: 2 x 3840 / 2 x 4096 frames). Interleaved timing
+with events, median of rounds; prints one JSON line per shape.   python scripts/conv_halo_bench.py [out.jsonl]"""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from distributed_rl_amd.ops import hip as H  # noqa: E402
+
+DEV = "cuda"
+SH = {2: ((20, 20, 32), (9, 9, 64), 512), 3: ((9, 9, 64), (7, 7, 64), 576)}
+
+
+def timeit(fns, rounds=7, iters=40):
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, fn in fns.items():
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            res[k].append(a.elapsed_time(b) * 1e3 / iters)
+    return {k: round(sorted(v)[len(v) // 2], 2) for k, v in res.items()}
+
+
+def main():
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    g = torch.Generator().manual_seed(0)
+    for layer in (2, 3):
+        ishape, oshape, K = SH[layer]
+        for f1, f2 in ((1024, 512), (512, 0), (3840, 3840), (4096, 4096)):
+            nets = []
+            for f in (f1, f2):
+                if not f:
+                    nets.append((None, 0, None, None, None))
+                    continue
+                x = torch.relu(torch.randn(f, *ishape, generator=g)).to(torch.bfloat16).to(DEV)
+                w = (torch.randn(64, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+                b = (torch.randn(64, generator=g) * 0.1).to(DEV)
+                o = torch.zeros(f, *oshape, dtype=torch.bfloat16, device=DEV)
+                nets.append((x, f, w, b, o))
+            (x1, _, w1, b1, o1), (x2, _, w2, b2, o2) = nets
+            fns = {}
+            for v in (0, 1):
+                fns["halo v%d" % v] = (lambda v=v: H.conv_halo_fwd(layer, x1, f1, w1, b1, o1, x2, f2, w2, b2, o2, variant=v))
+            if f2:
+                def tiled():
+                    H.native.hip().drl_conv_fwd_dual(layer, H._p(x1), f1, H._p(w1), H._p(b1), H._p(o1), H._p(x2), f2, H._p(w2),
+                                                     H._p(b2), H._p(o2), H._s())
+            else:
+                def tiled():
+                    H.conv_fwd(layer, x1, w1, b1, o1, f1, direct=False, variant=H.CONV_FWD_TILED_VARIANT[layer])
+            fns["tiled"] = tiled
+            t = timeit(fns)
+            flop = 2.0 * (f1 + f2) * oshape[0] * oshape[1] * 64 * K
+            row = {"layer": layer, "frames": [f1, f2], "us": t, "tflops": {k: round(flop / v / 1e6, 1) for k, v in t.items()}}
+            print(json.dumps(row), flush=True)
+            if out:
+                out.write(json.dumps(row) + "\n")
+
+
+if __name__ == "__main__":
+    main()

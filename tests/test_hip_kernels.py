@@ -487,6 +487,35 @@ def test_conv_fwd_dual(hip, layer, f1, f2):
         torch.testing.assert_close(o.float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("layer,variant", [(2, 0), (2, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("f1,f2", [(1, 0), (7, 0), (5, 3), (700, 0), (1024, 512), (1537, 700)])
+def test_conv_halo_fwd(hip, layer, variant, f1, f2):
+    """LDS-halo conv2 / conv3 (conv_halo.hip): one and two networks per launch, frame counts that are not multiples of
+    the frame group, more groups than persistent workgroups; a poisoned guard frame behind each output stays untouched."""
+    H = hip
+    nets = []
+    for f, seed in ((f1, 11), (f2, 13)):
+        if f == 0:
+            nets.append(None)
+            continue
+        x, xf, w, b, (cin, cout, ks, s, hw) = _conv_setup(layer, f, layer * 41 + f + seed)
+        oh = (hw - ks) // s + 1
+        o = torch.full((f + 1, oh, oh, cout), 7.0, dtype=torch.bfloat16, device=DEV)
+        nets.append((x.to(DEV), xf, w, b, o, s))
+    (x1, _, w1, b1, o1, _), n2 = nets[0], nets[1]
+    if n2 is None:
+        H.conv_halo_fwd(layer, x1, f1, w1.to(DEV), b1.to(DEV), o1, variant=variant)
+    else:
+        H.conv_halo_fwd(layer, x1, f1, w1.to(DEV), b1.to(DEV), o1, n2[0], f2, n2[2].to(DEV), n2[3].to(DEV), n2[4], variant=variant)
+    for net, f in zip(nets, (f1, f2)):
+        if net is None:
+            continue
+        x, xf, w, b, o, s = net
+        ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, stride=s)).permute(0, 2, 3, 1)
+        torch.testing.assert_close(o[:f].float().cpu(), ref, rtol=2e-2, atol=2e-2)
+        assert bool((o[f] == 7.0).all())
+
+
 @pytest.mark.parametrize("M1,M2", [(7, 3), (128, 64), (1024, 512)])
 def test_gemm_nt_and_head_dual(hip, M1, M2):
     H = hip
