@@ -20,6 +20,15 @@
 //   * The next group's frames are fetched global -> VGPR (coalesced, 16 B per lane) BEFORE the MFMAs of the current group
 //     and written to the second LDS image after them: the HBM / L2 latency hides under the compute, one barrier a round.
 //   * Two networks per launch (online + target of a learner step): the first nblk workgroups work on network 1.
+//
+// The INPUT GRADIENTS of conv3 / conv2 are convolutions too and run through the same kernel (MODE 1 / 2):
+//   conv3 dgrad: dx[9x9x64]  = 3x3 stride-1 convolution of dy[7x7x64] zero-padded by 2, flipped + transposed weights;
+//   conv2 dgrad: dx[20x20x32] = four 2x2 stride-1 convolutions (one per parity class (py, px) of the input pixel: the taps
+//                ky = py + 2 ty, kx = px + 2 tx) of dy[9x9x64] zero-padded by 1; wave w of the workgroup computes class w,
+//                so the staged frame is read once for all four classes.
+// The border of the LDS image is zeroed once per workgroup (the staging only ever writes the interior), the transformed
+// weights come from a tiny pre-pass (k_halo_wprep, once per optimizer step) and the epilogue multiplies with the ReLU mask
+// of the layer's input activation instead of adding a bias.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 halo_bf16x8;
@@ -32,43 +41,83 @@ __device__ __forceinline__ f32x4 halo_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ uint4 g_halo_dump[512 * 256];      // where the lanes of rows without a frame store (never read)
 
 struct HaloNet {
-    const bf16_t* x;       // [frames][IH][IW][CI]
-    const bf16_t* w;       // [64][KS][KS][CI]
-    const float* bias;     // [64]
-    bf16_t* out;           // [frames][OH][OW][64]
+    const bf16_t* x;       // [frames][SH][SW][CI] (MODE 0: the layer's input; MODE 1 / 2: dy)
+    const bf16_t* w;       // MODE 0: [64][KS][KS][CI]; MODE 1: wt3 [64 ci][3][3][64 co]; MODE 2: wt2 [4 classes][32 ci][2][2][64 co]
+    const float* bias;     // [64] (MODE 0)
+    const bf16_t* mask;    // MODE 1 / 2: the layer's input activation (ReLU mask of dx), laid out like out
+    bf16_t* out;           // MODE 0: [frames][OH][OW][64]; MODE 1: [frames][9][9][64]; MODE 2: [frames][20][20][32]
     int frames, nblk;      // workgroups that work on this network
 };
 
-// P / RP / FP: pixel, row and frame pitch of the LDS image in 16-byte slots. F frames per group, TC tiles per wave pass.
-template <int IH, int IW, int CI, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) {
+enum { HALO_FWD = 0, HALO_DGRAD = 1, HALO_DGRAD_S2 = 2 };
+
+// Weight pre-pass of the input-gradient kernels (MODE 1 / 2), once per optimizer step:
+//   wt3[ci][a][b][co] = w3[co][2 - a][2 - b][ci]                                            (64 x 576)
+//   wt2[py * 2 + px][ci][a][b][co] = w2[co][py + 2 (1 - a)][px + 2 (1 - b)][ci]              (4 x 32 x 256)
+// It rides along in the conv2 FORWARD launch of the training step (extra workgroups behind the convolution's: a launch
+// of its own costs more than the 140 KB it moves).
+struct HaloPrep {
+    const bf16_t* w2;
+    const bf16_t* w3;
+    bf16_t* wt2;
+    bf16_t* wt3;
+    int nblk;
+};
+constexpr int HALO_PREP_ELEMS = 64 * 576 + 4 * 32 * 256, HALO_PREP_BLOCKS = 34;      // 34 x 256 threads x 8 elements
+
+__device__ __forceinline__ void halo_wprep_elem(const HaloPrep& p, int i) {
+    if (i < 64 * 576) {
+        const int co = i & 63, b = (i >> 6) % 3, a = (i / 192) % 3, ci = i / 576;
+        p.wt3[i] = p.w3[((co * 3 + (2 - a)) * 3 + (2 - b)) * 64 + ci];
+    } else if (i < HALO_PREP_ELEMS) {
+        const int j = i - 64 * 576;
+        const int co = j & 63, b = (j >> 6) & 1, a = (j >> 7) & 1, ci = (j >> 8) & 31, cls = j >> 13, py = cls >> 1, px = cls & 1;
+        p.wt2[j] = p.w2[((co * 4 + py + 2 * (1 - a)) * 4 + px + 2 * (1 - b)) * 32 + ci];
+    }
+}
+
+// SH x SW x CI: source frame; PAD: zero border of the LDS image; P / RP / FP: pixel, row and frame pitch of the image in
+// 16-byte slots. F frames per group, TC tiles per wave pass.
+template <int SH, int SW, int CI, int PAD, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC, int MODE>
+__global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2, HaloPrep prep) {
+    constexpr int IH = SH + 2 * PAD, IW = SW + 2 * PAD;
     constexpr int OH = (IH - KS) / S + 1, OW = (IW - KS) / S + 1, OPX = OH * OW, K = KS * KS * CI, NS = K / 32;
     constexpr int CH = CI / 8, SPP = CI / 32;                  // 16-byte chunks per pixel, k-steps per tap
-    constexpr int NCHUNK = F * IH * IW * CH, NLD = (NCHUNK + 255) / 256;
-    constexpr int ROWS = F * OPX, NT = (ROWS + 15) / 16, NPASS = (NT + 2 * TC - 1) / (2 * TC);
+    constexpr int NCHUNK = F * SH * SW * CH, NLD = (NCHUNK + 255) / 256;
+    constexpr int WM = MODE == HALO_DGRAD_S2 ? 1 : 2;          // waves that share the tiles of a group
+    constexpr int CO = MODE == HALO_DGRAD_S2 ? 32 : 64;        // output channels per pixel
+    constexpr int ROWS = F * OPX, NT = (ROWS + 15) / 16, NPASS = (NT + WM * TC - 1) / (WM * TC);
     constexpr unsigned BUF = F * FP * 16;                      // bytes of one LDS image
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                  // two images of F * FP * 16 bytes
+    if (MODE == HALO_FWD && (int)blockIdx.x >= n1.nblk + n2.nblk) {                 // the weight pre-pass workgroups
+        const int b = (int)blockIdx.x - n1.nblk - n2.nblk;
+        for (int i = b * 256 + (int)threadIdx.x; i < HALO_PREP_ELEMS; i += prep.nblk * 256) halo_wprep_elem(prep, i);
+        return;
+    }
     const bool second = (int)blockIdx.x >= n1.nblk;            // block-uniform
     const bf16_t* __restrict__ x = second ? n2.x : n1.x;
     const bf16_t* __restrict__ w = second ? n2.w : n1.w;
     const float* __restrict__ bias = second ? n2.bias : n1.bias;
+    const bf16_t* __restrict__ mask = second ? n2.mask : n1.mask;
     bf16_t* __restrict__ out = second ? n2.out : n1.out;
     const int frames = second ? n2.frames : n1.frames, nblk = second ? n2.nblk : n1.nblk;
     const int blk = second ? (int)blockIdx.x - n1.nblk : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = MODE == HALO_DGRAD_S2 ? 0 : wave >> 1, wn = MODE == HALO_DGRAD_S2 ? 0 : wave & 1;
+    const int py = wave >> 1, px = wave & 1;                   // MODE 2: the wave's parity class
     const int ngroups = (frames + F - 1) / F;
     if (blk >= ngroups) return;                                 // block-uniform, before any barrier
 
     // next group's frames: global -> registers (chunks past the last frame re-read its last chunk; their rows are never stored)
     u32x4 st[NLD];
     auto gload = [&](int grp) {
-        const long long base = (long long)grp * F * (IH * IW * CI);
-        const int nvalid = min(F, frames - grp * F) * (IH * IW * CH);
+        const long long base = (long long)grp * F * (SH * SW * CI);
+        const int nvalid = min(F, frames - grp * F) * (SH * SW * CH);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int j = tid + i * 256;
-            st[i] = *reinterpret_cast<const u32x4*>(x + base + (long long)min(j, nvalid - 1) * 8);   
+            st[i] = *reinterpret_cast<const u32x4*>(x + base + (long long)min(j, nvalid - 1) * 8);
         }
     };
     auto lstore = [&](uint8_t* img) {
@@ -76,8 +125,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
         for (int i = 0; i < NLD; ++i) {
             const int j = tid + i * 256;
             if (NCHUNK % 256 == 0 || j < NCHUNK) {
-                const int pix = j / CH, c = j - pix * CH, f = pix / (IH * IW), rem = pix - f * (IH * IW), y = rem / IW, xx = rem - y * IW;
-                *reinterpret_cast<u32x4*>(img + (size_t)(f * FP + y * RP + xx * P + c) * 16) = st[i];
+                const int pix = j / CH, c = j - pix * CH, f = pix / (SH * SW), rem = pix - f * (SH * SW), y = rem / SW, xx = rem - y * SW;
+                *reinterpret_cast<u32x4*>(img + (size_t)(f * FP + (y + PAD) * RP + (xx + PAD) * P + c) * 16) = st[i];
             }
         }
     };
@@ -86,17 +135,26 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
 
     // weights -> registers (A operand: lane supplies W[row l%16][k-step s, k = (l/16)*8 ..])
     bf16x8 wf[2][NS];
+    {
+        const bf16_t* wb = w + (size_t)(MODE == HALO_DGRAD_S2 ? wave * 32 : 32 * wn) * K;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            wf[t][s] = *reinterpret_cast<const bf16x8*>(w + (size_t)(32 * wn + (r >> 2) * 8 + t * 4 + (r & 3)) * K + s * 32 + g * 8);
-    float4 b4[2];
+            for (int s = 0; s < NS; ++s)
+                wf[t][s] = *reinterpret_cast<const bf16x8*>(wb + (size_t)((r >> 2) * 8 + t * 4 + (r & 3)) * K + s * 32 + g * 8);
+    }
+    float4 b4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (MODE == HALO_FWD) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + 32 * wn + g * 8 + t * 4);
+        for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + 32 * wn + g * 8 + t * 4);
+    }
+    if (PAD > 0) {                                              // zero both images once: the staging never writes the border
+        for (unsigned i = tid; i < 2 * BUF / 16; i += 256) *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
     // Land weights and bias HERE, once: left to the compiler their waits sit at the first use inside the group loop as
-    // counted vmcnt(N) that ignore the (conditional) prefetch below, so every later round would wait for most of its
-    // prefetch in the middle of the MFMAs.
+    // counted vmcnt(N) that ignore the prefetch below, so every later round would wait for most of its prefetch in the
+    // middle of the MFMAs.
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -106,10 +164,8 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
 
     // Round = one frame group. Two LDS images: the MFMAs of round i read image i % 2 while the frames of round i + 1,
     // fetched into registers at the top of the round, are written to the other image right after the K loop and BEFORE
-    // the round's output stores are issued. (Loads and stores share vmcnt but may retire out of order with respect to
-    // each other, so the compiler turns any wait for a load into vmcnt(0) while a store is in flight: with the staging
-    // wait placed after the stores every round would start with a drain of its predecessor's output stores. Here the
-    // only stores in flight at the wait are a whole K loop old.) One barrier per round.
+    // the round's output stores are issued: the only stores in flight at the staging wait are a whole K loop old.
+    // One barrier per round.
     lstore(smem);
     unsigned cur = 0;
     for (; grp < ngroups; grp += nblk) {
@@ -121,17 +177,30 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
         gload(min(grp + nblk, ngroups - 1));
         __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ABOVE the compute
         const int rows = F == 1 ? OPX : min(F, frames - grp * F) * OPX;
-        const long long obase = (long long)grp * ROWS * 64;
         f32x4 acc[NPASS][TC][2];
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            const int tile0 = wm * TC + pass * 2 * TC;
+            const int tile0 = wm * TC + pass * WM * TC;
             unsigned xb[TC];
+            long long oaddr[TC];                                // element offset of this lane's 8 output channels
+            bool live[TC];
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
+                // rows past the end of the tile range are computed from the inputs of row ROWS - 1 and store the same
+                // values to the same place; rows of frames that do not exist go to the dump page
                 const int m = min((tile0 + u) * 16 + r, ROWS - 1);
                 const int f = m / OPX, rem = m - f * OPX, oy = rem / OW, ox = rem - oy * OW;
                 xb[u] = cur * BUF + (unsigned)(f * FP + (S * oy) * RP + (S * ox) * P + g) * 16u;
+                live[u] = F == 1 || m < rows;
+                if (MODE == HALO_DGRAD_S2)
+                    oaddr[u] = ((long long)(grp * F + f) * (4 * OPX) + (2 * oy + py) * (2 * OW) + 2 * ox + px) * CO + g * 8;
+                else
+                    oaddr[u] = ((long long)grp * ROWS + m) * CO + 32 * wn + g * 8;
+            }
+            u32x4 mk[TC];                                       // ReLU mask of dx: loaded before the K loop, used after it
+            if (MODE != HALO_FWD) {
+#pragma unroll
+                for (int u = 0; u < TC; ++u) mk[u] = *reinterpret_cast<const u32x4*>(mask + (live[u] ? oaddr[u] : 0));
             }
 #pragma unroll
             for (int u = 0; u < TC; ++u) acc[pass][u][0] = acc[pass][u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -166,17 +235,25 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
             }
 #pragma unroll
             for (int u = 0; u < TC; ++u) {
-                // rows past the end of the tile range were computed from the inputs of row ROWS - 1 (same clamp as xb):
-                // they store the same values to the same place; rows of frames that do not exist go to the dump page
-                const int m = min((tile0 + u) * 16 + r, ROWS - 1);
                 u32x4 o;
+                if (MODE == HALO_FWD) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    o[2 * t] = pack_bf2(fmaxf(acc[pass][u][t][0] + b4[t].x, 0.f), fmaxf(acc[pass][u][t][1] + b4[t].y, 0.f));
-                    o[2 * t + 1] = pack_bf2(fmaxf(acc[pass][u][t][2] + b4[t].z, 0.f), fmaxf(acc[pass][u][t][3] + b4[t].w, 0.f));
+                    for (int t = 0; t < 2; ++t) {
+                        o[2 * t] = pack_bf2(fmaxf(acc[pass][u][t][0] + b4[t].x, 0.f), fmaxf(acc[pass][u][t][1] + b4[t].y, 0.f));
+                        o[2 * t + 1] = pack_bf2(fmaxf(acc[pass][u][t][2] + b4[t].z, 0.f), fmaxf(acc[pass][u][t][3] + b4[t].w, 0.f));
+                    }
+                } else {                                            // dx = relu'(act_in) * acc: a positive bf16 has a non-zero
+#pragma unroll                                                     // word and a clear sign bit
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t mw = mk[u][2 * t + h];
+                            const bool lo = (mw & 0xffffu) != 0 && !(mw & 0x8000u), hi = (mw >> 16) != 0 && !(mw & 0x80000000u);
+                            o[2 * t + h] = pack_bf2(lo ? acc[pass][u][t][2 * h] : 0.f, hi ? acc[pass][u][t][2 * h + 1] : 0.f);
+                        }
                 }
-                bf16_t* dst = out + obase + (long long)m * 64 + 32 * wn + g * 8;
-                if (F > 1) dst = m < rows ? dst : reinterpret_cast<bf16_t*>(g_halo_dump + ((blockIdx.x & 511) * 256 + tid));
+                bf16_t* dst = out + oaddr[u];
+                if (F > 1) dst = live[u] ? dst : reinterpret_cast<bf16_t*>(g_halo_dump + ((blockIdx.x & 511) * 256 + tid));
                 *reinterpret_cast<u32x4*>(dst) = o;
             }
         }
@@ -184,10 +261,11 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2) 
     }
 }
 
-template <int IH, int IW, int CI, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC>
-static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s) {
+template <int SH, int SW, int CI, int PAD, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC, int MODE>
+static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s, HaloPrep prep = HaloPrep{nullptr, nullptr, nullptr, nullptr, 0}) {
     constexpr int LDS = 2 * F * FP * 16;
-    auto kern = k_conv_halo<IH, IW, CI, KS, S, P, RP, FP, F, TC, OCC>;
+    static_assert(LDS * OCC <= 160 * 1024, "LDS images of the resident workgroups");
+    auto kern = k_conv_halo<SH, SW, CI, PAD, KS, S, P, RP, FP, F, TC, OCC, MODE>;
     static bool once = ((void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
     (void)once;
     // persistent workgroups: OCC per CU, dealt to the two networks in proportion to their frames
@@ -205,7 +283,7 @@ static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s) {
     auto even = [](int groups, int blocks) { const int rounds = (groups + blocks - 1) / blocks; return (groups + rounds - 1) / rounds; };
     n1.nblk = even(g1, b1);
     n2.nblk = g2 ? even(g2, b2) : 0;
-    kern<<<n1.nblk + n2.nblk, 256, LDS, s>>>(n1, n2);
+    kern<<<n1.nblk + n2.nblk + prep.nblk, 256, LDS, s>>>(n1, n2, prep);
     return (int)hipGetLastError();
 }
 
@@ -213,17 +291,42 @@ static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s) {
 // frames2 = 0: one network. variant: 0 = two workgroups per CU, 1 = one workgroup per CU (wider tile pass)
 DRL_API int drl_conv_halo_fwd(int layer, const void* x1, int frames1, const void* w1, const float* bias1, void* out1,
                               const void* x2, int frames2, const void* w2, const float* bias2, void* out2, int variant,
-                              hipStream_t s) {
+                              const void* prep_w2, const void* prep_w3, void* prep_wt2, void* prep_wt3, hipStream_t s) {
     if (frames1 <= 0 || frames2 < 0) return -1;
-    HaloNet n1{(const bf16_t*)x1, (const bf16_t*)w1, bias1, (bf16_t*)out1, frames1, 0};
-    HaloNet n2{(const bf16_t*)x2, (const bf16_t*)w2, bias2, (bf16_t*)out2, frames2, 0};
+    // prep_wt2 != null (layer 2 only): also write the flipped / transposed weights of the input-gradient kernels
+    HaloPrep prep{(const bf16_t*)prep_w2, (const bf16_t*)prep_w3, (bf16_t*)prep_wt2, (bf16_t*)prep_wt3, prep_wt2 ? HALO_PREP_BLOCKS : 0};
+    if (prep.nblk && (layer != 2 || !prep_w2 || !prep_w3 || !prep_wt3)) return -1;
+    HaloNet n1{(const bf16_t*)x1, (const bf16_t*)w1, bias1, nullptr, (bf16_t*)out1, frames1, 0};
+    HaloNet n2{(const bf16_t*)x2, (const bf16_t*)w2, bias2, nullptr, (bf16_t*)out2, frames2, 0};
     if (layer == 2) {
-        if (variant == 1) return launch_halo<20, 20, 32, 4, 2, 5, 101, 2020, 1, 3, 1>(n1, n2, s);
-        return launch_halo<20, 20, 32, 4, 2, 5, 101, 2020, 1, 3, 2>(n1, n2, s);
+        if (variant == 1) return launch_halo<20, 20, 32, 0, 4, 2, 5, 101, 2020, 1, 3, 1, HALO_FWD>(n1, n2, s, prep);
+        return launch_halo<20, 20, 32, 0, 4, 2, 5, 101, 2020, 1, 3, 2, HALO_FWD>(n1, n2, s, prep);
     }
     if (layer == 3) {
-        if (variant == 1) return launch_halo<9, 9, 64, 3, 1, 10, 102, 922, 3, 5, 1>(n1, n2, s);
-        return launch_halo<9, 9, 64, 3, 1, 10, 102, 922, 2, 2, 2>(n1, n2, s);
+        if (variant == 1) return launch_halo<9, 9, 64, 0, 3, 1, 10, 102, 922, 3, 5, 1, HALO_FWD>(n1, n2, s);
+        return launch_halo<9, 9, 64, 0, 3, 1, 10, 102, 922, 2, 2, 2, HALO_FWD>(n1, n2, s);
     }
+    return -1;
+}
+
+// ---- input gradients ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_wprep(HaloPrep p) {
+    halo_wprep_elem(p, blockIdx.x * 256 + threadIdx.x);
+}
+
+DRL_API int drl_conv_halo_wprep(const void* w2, const void* w3, void* wt2, void* wt3, hipStream_t s) {
+    k_halo_wprep<<<(HALO_PREP_ELEMS + 255) / 256, 256, 0, s>>>(HaloPrep{(const bf16_t*)w2, (const bf16_t*)w3, (bf16_t*)wt2, (bf16_t*)wt3, 0});
+    return (int)hipGetLastError();
+}
+
+// layer 3: dy bf16 [n,7,7,64], wt = wt3, act_in / dx bf16 [n,9,9,64]; layer 2: dy bf16 [n,9,9,64], wt = wt2, act_in / dx bf16
+// [n,20,20,32]. dx = relu'(act_in) * conv_transpose(dy, w).
+DRL_API int drl_conv_halo_dgrad(int layer, const void* dy, int frames, const void* wt, const void* act_in, void* dx, hipStream_t s) {
+    if (frames <= 0 || !act_in) return -1;
+    HaloNet n1{(const bf16_t*)dy, (const bf16_t*)wt, nullptr, (const bf16_t*)act_in, (bf16_t*)dx, frames, 0};
+    HaloNet n2{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    // image pitches from scripts/debug/halo_lds_layout.py (conflict-free for every tile and tap)
+    if (layer == 3) return launch_halo<7, 7, 64, 2, 3, 1, 10, 122, 1354, 3, 4, 1, HALO_DGRAD>(n1, n2, s);
+    if (layer == 2) return launch_halo<9, 9, 64, 1, 2, 1, 10, 116, 1276, 1, 7, 2, HALO_DGRAD_S2>(n1, n2, s);
     return -1;
 }

@@ -1232,6 +1232,17 @@ DRL_API int drl_conv_bwd(int layer, const void* x, const long long* frame_off, i
         return conv_bwd_12<GemmBody<32, 64, 128, 1, 4, true, true, 4, DenseOp, Conv1Op>>(Conv1Op{x, nullptr, rows}, 32, Conv1Op::K,
                                                                                        1.0f / 255.0f, dy, dw, db, splits, extra, sample, s);
     }
+    // dx == null (layers 2 / 3): weight + bias gradient (+ extra) only; the input gradient runs in the LDS-halo kernel
+    // (conv_halo.hip, drl_conv_halo_dgrad)
+    if (!dx) {
+        const int wv = variant < 3 ? variant : (variant == 3 ? 1 : (variant == 4 ? 2 : 0));   // wgrad body of the fused variant
+#define CW(COp, bk, d) return conv_bwd_12<GemmBody<64, 64, bk, 2, 2, true, true, d, DenseOp, COp>>(COp{x, nullptr, frames * COp::OH * COp::OW}, \
+                                                                                                   64, COp::K, 1.0f, dy, dw, db, splits, extra, nullptr, s)
+        if (layer == 2) { if (wv == 0) CW(Conv2Op, 128, 2); if (wv == 1) CW(Conv2Op, 64, 4); CW(Conv2Op, 64, 2); }
+        if (layer == 3) { if (wv == 0) CW(Conv3Op, 128, 2); if (wv == 1) CW(Conv3Op, 64, 4); CW(Conv3Op, 64, 2); }
+#undef CW
+        return -1;
+    }
 #define CB2(bk, d, f) return conv_bwd_3<20, 20, 4, 2, 32, 64, 128, 32, 4, 1, Conv2Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)
 #define CB3(bk, d, f) return conv_bwd_3<9, 9, 3, 1, 64, 64, 128, 64, 2, 2, Conv3Op, bk, d, f>(x, frames, dy, w, dw, db, dx, splits, extra, s)
     // variant (tuning hook): K-tile / ring depth of the weight-gradient body and the order of the bodies. The launch

@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (gd.g[k] && *gd.g[k]) f |= 1 << k;
         *fault = f;
+        // host mirror: fault[2..3] hold the address of a pinned, device-mapped host word (engine/guard.py). Written from
+        // here - a memcpy node of the step graph for these 4 bytes costs 4 us per step
+        int* mirror = reinterpret_cast<int*>(*reinterpret_cast<const unsigned long long*>(fault + 2));
+        if (mirror) __hip_atomic_store(mirror, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     float acc = 0.f;
     const long long n4 = n >> 2;

@@ -18,6 +18,7 @@ reference's format.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -59,7 +60,7 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
                        off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers,
-                       shared_tail: bool = False) -> None:
+                       shared_tail: bool = False, prep=None) -> None:
     """Forward of TWO networks (online on n1 frames, target on n2 frames), 5 launches in total: each layer of both networks
     is one launch, so the learner's step needs no second stream (no fork / join) for the target network."""
     if shared_tail and n1 == 2 * n2:
@@ -72,7 +73,8 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
                         wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
-                        getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst))
+                        getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst),
+                        prep=prep if l == 2 else None)
     H.gemm_nt_dual(b1.act3, wb1.view("fc1.w"), wf1.view("fc1.b"), b1.h, b2.act3, wb2.view("fc1.w"), wf2.view("fc1.b"), b2.h,
                    1024, 3136, flags=H.EPI_RELU)
     H.head_fwd_dual(b1.h, wb1.view("adv2.w"), wf1.view("adv2.b"), wb1.view("val2.w"), wf1.view("val2.b"), b1.q,
@@ -115,21 +117,29 @@ class ApexEngine(ShardedIS):
         self.d2 = torch.zeros(B * 81, 64, **bf)          # d conv2 pre-activation
         self.dcol2 = torch.zeros(B * 81, 512, **bf)
         self.d1 = torch.zeros(B * 400, 32, **bf)         # d conv1 pre-activation
+        # input gradients of conv3 / conv2 through the LDS-halo kernel: flipped / transposed weight copies, rewritten by
+        # extra workgroups of every step's conv2 forward launch (ops.hip.conv_halo_fwd(prep=...))
+        # At B = 512 the fused launch (dX + dW + db bodies share the chip) still wins: 0.2278 ms per step against 0.2297 ms
+        # with the halo dX + a dW launch per layer, and 0.2362 ms with the dW launches on a side stream (fork / join edges
+        # of the replayed graph cost more than the overlap gains). The halo dX kernels pay from ~1000 frames per launch
+        # (R2D2: 2.18 -> 2.13 ms), so: by batch size.
+        self.halo_bwd = H.CONV_HALO_BWD and (B >= 1024 or os.environ.get("DRL_CONV_HALO_BWD") == "force")
+        self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
+        self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self._init_shard(replay, dist, dev)              # self.n_is: device scalar N_global / world (engine/shard.py)
-        import os as _os
-        self.overlap_comm = _os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
-        self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
+        self.overlap_comm = os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
+        self.fused_bwd = os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
         # software-pipelined sampler (needs the fused path: step_end must have run before the optimizer launch)
-        self.presample = self.fused_bwd and B % 4 == 0 and _os.environ.get("DRL_PRESAMPLE", "1") != "0"
+        self.presample = self.fused_bwd and B % 4 == 0 and os.environ.get("DRL_PRESAMPLE", "1") != "0"
         if self.presample:
             replay._next_buffers()                                        # allocate now, never inside a graph capture
-        self.dual_fwd = _os.environ.get("DRL_DUAL_FWD", "1") != "0"       # online + target forward as one launch per layer
+        self.dual_fwd = os.environ.get("DRL_DUAL_FWD", "1") != "0"       # online + target forward as one launch per layer
         # s' read + converted once for the online and the target conv1 (two weight sets per tile in part of the launch):
         # measured SLOWER here (0.2465 vs 0.2400 ms: the heavier pair blocks set the launch's registers and its tail), off
-        self.conv1_pair = _os.environ.get("DRL_APEX_CONV1_PAIR", "0") != "0"
+        self.conv1_pair = os.environ.get("DRL_APEX_CONV1_PAIR", "0") != "0"
         self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
@@ -167,10 +177,13 @@ class ApexEngine(ShardedIS):
         # presample: from the second step on the batch was already drawn by the previous step's optimizer launch.
         if not (self.presample and self._primed):
             r.sample(self.st, begin=True, is_n_scale=1.0 if self.fused_bwd else 0.0, n_is=self.n_is)
+        prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None
         if self.dual_fwd:
             torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
-                               shared_tail=self.conv1_pair)
+                               shared_tail=self.conv1_pair, prep=prep)
         else:
+            if prep is not None:
+                H.conv_halo_wprep(*prep)
             with self._fork(0):                                    # target net on s' || online net on [s ; s']
                 torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
             torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
@@ -208,10 +221,15 @@ class ApexEngine(ShardedIS):
         if self.fused_bwd:                                         # dX + dW + db of a layer = one launch
             # the PER priority write-back (needs only the TD kernel's output) rides along as an extra body: leaves +
             # level 1 inside the conv3 launch, upper levels + step_end inside the conv2 launch
-            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), self.d2, B, splits=sp,
-                       extra=r.update_stage(1, self.new_prio))
-            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), self.d1, B, splits=sp,
-                       extra=r.update_stage(2, self.new_prio, end_state=self.st))
+            halo = self.halo_bwd                                   # dX in the LDS-halo kernel, dW + db (+ extra) in k_multi
+            if halo:
+                H.conv_halo_dgrad(3, self.d3, self.wt3, a2, self.d2, B)
+            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else self.d2,
+                       B, splits=sp, extra=r.update_stage(1, self.new_prio))
+            if halo:
+                H.conv_halo_dgrad(2, self.d2, self.wt2, a1, self.d1, B)
+            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else self.d1,
+                       B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st))
             # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
             # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
             # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.

@@ -5,8 +5,8 @@ with BOUNDED polls: a poll that gives up sets a device word and the kernel finis
 hanging the GPU. Those words are the ``guards`` of the step. The first optimizer launch folds them into a sticky
 ``fault`` word; the update launch and the priority write-back read it and do nothing when it is set, so a poisoned
 gradient never reaches the parameters, the optimizer moments or the replay priorities - this step and every later one
-are discarded. A pinned host mirror of the word is refreshed by an asynchronous copy at the end of every step (a memcpy
-node of the step graph), and ``check()`` - called at the top of ``step()`` without synchronising - raises as soon as
+are discarded. A pinned host mirror of the word is written by the same launch (a system-scope store to device-mapped host
+memory: a memcpy node of the step graph for these 4 bytes cost 4 us per step), and ``check()`` - called at the top of ``step()`` without synchronising - raises as soon as
 the mirror shows it, i.e. at most the host's run-ahead (a few steps) later.
 """
 from __future__ import annotations
@@ -20,8 +20,12 @@ class StepGuard:
     NAMES_MAX = 4
 
     def __init__(self, device):
-        self.fault = torch.zeros(4, dtype=torch.int32, device=device)      # [0] = sticky bit mask of the guards that fired
+        # [0] = sticky bit mask of the guards that fired, [2:4] = address of the pinned host mirror (written by the kernel
+        # that folds the guards: k_sumsq_partial, optim.hip)
+        self.fault = torch.zeros(4, dtype=torch.int32, device=device)
         self.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        if torch.device(device).type == "cuda":
+            self.fault[2:4].copy_(torch.tensor([self.host.data_ptr()], dtype=torch.int64).view(torch.int32))
         self.sources: List = []
         self.names: List[str] = []
 
@@ -34,8 +38,7 @@ class StepGuard:
         self.names.append(name)
 
     def mirror(self) -> None:
-        """Inside the step, after the optimizer launches: fault word -> pinned host memory, asynchronously."""
-        self.host.copy_(self.fault, non_blocking=True)
+        """Nothing to launch: the kernel that folds the guards also stores the fault word to the pinned host mirror."""
 
     def fired(self) -> List[str]:
         m = int(self.host[0])

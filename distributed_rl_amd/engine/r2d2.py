@@ -62,7 +62,7 @@ def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
 
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
                       wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None,
-                      persistent: bool = False) -> None:
+                      persistent: bool = False, prep=None) -> None:
     """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
     all T) + ONE input-projection GEMM for those steps (throughput-bound). ``persistent``: the recurrence that follows is
     the persistent kernel (it may take over the bias add, see defer_xg_bias)."""
@@ -72,7 +72,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     fo = frame_off[r0:r1] if frame_off is not None else None
     a1, a2, a3 = buf.act1[r0:r1], buf.act2[r0:r1], buf.act3[r0:r1]
     H.conv_fwd(1, x, wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
-    H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n)
+    H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n, prep=prep if t0 == 0 else None)
     H.conv_fwd(3, a2, wb.view("conv3.w"), wf.view("conv3.b"), a3, n)
     if t0 == 0:
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
@@ -88,7 +88,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
 
 
 def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
-                           steps: Tuple[int, int], persistent: bool) -> None:
+                           steps: Tuple[int, int], persistent: bool, prep=None) -> None:
     """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target), each conv layer as one
     launch (the second network's read of a frame finds it in the Infinity Cache). net = (wb, wf, buf, bsum)."""
     t0, t1 = steps
@@ -103,7 +103,8 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
                         wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
-                        getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1])
+                        getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1],
+                        prep=prep if (l == 2 and t0 == 0) else None)
     if t0 == 0:
         for wb, wf, buf, bsum in (net1, net2):
             H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
@@ -217,6 +218,9 @@ class R2D2Engine(ShardedIS):
         self.d2 = torch.zeros(NB * 81, 64, **bf)
         self.dcol2 = torch.zeros(NB * 81, 512, **bf)
         self.d1 = torch.zeros(NB * 400, 32, **bf)
+        self.halo_bwd = H.CONV_HALO_BWD                  # conv3 / conv2 input gradients through the LDS-halo kernel
+        self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
+        self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
         _os = os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
@@ -292,6 +296,12 @@ class R2D2Engine(ShardedIS):
             H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0])
         else:
             H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0])
+        # pre-transformed conv2 / conv3 weights of the LDS-halo input-gradient kernels: written by extra workgroups of the
+        # first conv2 forward launch of the step (or by a launch of their own when that forward is not the halo kernel)
+        prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None
+        if prep is not None and not H.CONV_HALO:
+            H.conv_halo_wprep(*prep)
+            prep = None
         if pipelined:
             # PIPELINED over time chunks: the torso of chunk k+1 (throughput-bound, all CUs) runs while the recurrences
             # of chunk k (latency-bound, 32 workgroups per net) chase it on two side streams, so the forward costs about
@@ -303,10 +313,10 @@ class R2D2Engine(ShardedIS):
                 pl = self.persistent_lstm
                 if dual and self.dual_torso:
                     seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
-                                           (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl)
+                                           (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep)
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
-                                      persistent=pl)
+                                      persistent=pl, prep=prep)
                     if not dual:
                         with fj.fork(0):
                             seq_recurrence(T, B, Hd, self.Pb, self.on, pl, steps=st_, bsum=self.bsum_on)
@@ -346,7 +356,7 @@ class R2D2Engine(ShardedIS):
                     seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
         else:
             seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on,
-                              persistent=self.persistent_lstm)
+                              persistent=self.persistent_lstm, prep=prep)
             with fj.fork(0):                                        # target net: queued behind the online torso
                 self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
             seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm, bsum=self.bsum_on)
@@ -446,9 +456,14 @@ class R2D2Engine(ShardedIS):
             H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
         if self.fused_bwd:                                          # dX + dW + db of a conv layer = one launch (k_multi)
             # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
-            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), d2, n, splits=sp,
+            halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
+            if halo:
+                H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
+            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else d2, n, splits=sp,
                        variant=4 if n >= 2048 else None)
-            H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), d1, n, splits=sp)
+            if halo:
+                H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
+            H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
             H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
                        frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
             return

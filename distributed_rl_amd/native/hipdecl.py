@@ -40,7 +40,9 @@ SIGS = {
     # conv_direct.hip
     "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
     # conv_halo.hip
-    "drl_conv_halo_fwd": [I, P, I, P, P, P, P, I, P, P, P, I, P],
+    "drl_conv_halo_fwd": [I, P, I, P, P, P, P, I, P, P, P, I, P, P, P, P, P],
+    "drl_conv_halo_wprep": [P, P, P, P, P],
+    "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
     "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
     "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P, P],

@@ -353,14 +353,19 @@ CONV_FWD_TILED_VARIANT = {2: 0, 3: 1}
 # conv2 / conv3 forward through the LDS-halo kernels (conv_halo.hip: whole input frames staged in LDS once, weights in
 # registers). DRL_CONV_HALO=0 falls back to the implicit-GEMM tiles of gemm.hip (A/B switch).
 CONV_HALO = os.environ.get("DRL_CONV_HALO", "1") != "0"
+# ... and their input gradients (zero-padded dy through the same kernel, pre-transformed weights written by extra
+# workgroups of the conv2 forward launch); the weight / bias gradients stay in the k_multi launch without its dgrad body
+CONV_HALO_BWD = CONV_HALO and os.environ.get("DRL_CONV_HALO_BWD", "1") != "0"
 # variant 0 = two workgroups per CU, 1 = one per CU. Measured (scripts/conv_halo_bench.py, us, v0 / v1 / implicit GEMM):
 #   conv2 1024+512 frames 19.2 / 17.9 / 24.5, 2 x 3840 frames 48.7 / 54.6 / 95.0;  conv3 15.5 (v1) / 20.3, 34.2 (v1) / 62.8
 CONV_HALO_VARIANT = {2: int(os.environ.get("DRL_CONV2_HALO_VARIANT", "-1")), 3: int(os.environ.get("DRL_CONV3_HALO_VARIANT", "1"))}
 
 
 def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w2=None, b2=None, out2=None,
-                  variant: Optional[int] = None) -> None:
-    """conv2 / conv3 (+bias+ReLU) of one or two networks in one launch of the LDS-halo kernel."""
+                  variant: Optional[int] = None, prep=None) -> None:
+    """conv2 / conv3 (+bias+ReLU) of one or two networks in one launch of the LDS-halo kernel. prep (layer 2 only) = (w2, w3,
+    wt2, wt3): extra workgroups of the launch also write the pre-transformed weights of the input-gradient kernels
+    (conv_halo_wprep without a launch of its own)."""
     assert layer in (2, 3)
     ci, co = ((20 * 20 * 32, 81 * 64) if layer == 2 else (81 * 64, 49 * 64))
     for x, f, w, b, o in ((x1, f1, w1, b1, out1),) + (((x2, f2, w2, b2, out2),) if f2 else ()):
@@ -369,19 +374,44 @@ def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w
     v = CONV_HALO_VARIANT[layer] if variant is None else variant
     if v < 0:
         v = 1 if f1 + f2 <= 2048 else 0
+    pw2, pw3, pwt2, pwt3 = prep if prep is not None else (None, None, None, None)
+    if prep is not None:
+        assert layer == 2
+        for t, n in ((pw2, 64 * 512), (pw3, 64 * 576), (pwt2, 64 * 512), (pwt3, 64 * 576)):
+            _chk(t, torch.bfloat16, "prep"); assert t.numel() == n
     _ck(native.hip().drl_conv_halo_fwd(layer, _p(x1), f1, _p(w1), _p(b1), _p(out1), _p(x2) if f2 else None, f2,
-                                       _p(w2) if f2 else None, _p(b2) if f2 else None, _p(out2) if f2 else None, v, _s()),
-        "conv_halo_fwd")
+                                       _p(w2) if f2 else None, _p(b2) if f2 else None, _p(out2) if f2 else None, v,
+                                       _p(pw2), _p(pw3), _p(pwt2), _p(pwt3), _s()), "conv_halo_fwd")
+
+
+def conv_halo_wprep(w2: torch.Tensor, w3: torch.Tensor, wt2: torch.Tensor, wt3: torch.Tensor) -> None:
+    """Flipped / transposed copies of the conv2 and conv3 weights for the LDS-halo input-gradient kernels (one tiny launch;
+    the learners run it once per optimizer step): wt2 bf16 [4, 32, 2, 2, 64], wt3 bf16 [64, 3, 3, 64]."""
+    for t, n in ((w2, 64 * 512), (w3, 64 * 576), (wt2, 64 * 512), (wt3, 64 * 576)):
+        _chk(t, torch.bfloat16, "w"); assert t.numel() == n
+    _ck(native.hip().drl_conv_halo_wprep(_p(w2), _p(w3), _p(wt2), _p(wt3), _s()), "conv_halo_wprep")
+
+
+def conv_halo_dgrad(layer: int, dy: torch.Tensor, wt: torch.Tensor, act_in: torch.Tensor, dx: torch.Tensor, frames: int) -> None:
+    """dx = relu'(act_in) * conv_transpose(dy, w) of conv2 / conv3 as a stride-1 convolution of the zero-padded dy through
+    the LDS-halo kernel; wt = the layer's pre-transformed weights (conv_halo_wprep)."""
+    assert layer in (2, 3)
+    ny, nx = ((81 * 64, 400 * 32) if layer == 2 else (49 * 64, 81 * 64))
+    _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt"); _chk(act_in, torch.bfloat16, "act_in"); _chk(dx, torch.bfloat16, "dx")
+    assert dy.numel() >= frames * ny and act_in.numel() >= frames * nx and dx.numel() >= frames * nx
+    assert wt.numel() == 64 * (512 if layer == 2 else 576)
+    _ck(native.hip().drl_conv_halo_dgrad(layer, _p(dy), frames, _p(wt), _p(act_in), _p(dx), _s()), "conv_halo_dgrad")
 
 
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
              frame_off: Optional[torch.Tensor] = None, relu: bool = True, direct: Optional[bool] = None,
-             variant: int = 0) -> None:
+             variant: int = 0, prep=None) -> None:
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
     _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
     if layer != 1 and CONV_HALO and relu and direct is None:
-        conv_halo_fwd(layer, x, frames, w, bias, out)
+        conv_halo_fwd(layer, x, frames, w, bias, out, prep=prep)
         return
+    assert prep is None
     if ((layer in CONV_FWD_DIRECT) if direct is None else direct) and relu:
         _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
             "conv_fwd_direct")
@@ -391,7 +421,8 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
                                   (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
 
 
-def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None) -> None:
+def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None,
+                  prep=None) -> None:
     """Forward of one conv layer (+bias+ReLU) of TWO networks in one launch (Ape-X learner: online net on [s ; s'] and
     target net on s'). layer 1: x1 is the frame store, x2 is ignored, the two nets gather through frame_off1 / frame_off2."""
     for w, b, o in ((w1, b1, out1), (w2, b2, out2)):
@@ -403,8 +434,9 @@ def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, ou
         return
     _chk(x1, torch.bfloat16, "x1"); _chk(x2, torch.bfloat16, "x2")
     if CONV_HALO:
-        conv_halo_fwd(layer, x1, f1, w1, b1, out1, x2, f2, w2, b2, out2)
+        conv_halo_fwd(layer, x1, f1, w1, b1, out1, x2, f2, w2, b2, out2, prep=prep)
         return
+    assert prep is None
     _ck(native.hip().drl_conv_fwd_dual(layer, _p(x1), f1, _p(w1), _p(b1), _p(out1), _p(x2), f2, _p(w2), _p(b2), _p(out2), _s()),
         "conv_fwd_dual")
 
@@ -566,7 +598,9 @@ def conv_bwd(layer: int, x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Te
     x = the layer's forward input (layer 1: uint8 frames, optionally via frame_off byte offsets)."""
     _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
     if layer != 1:
-        _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
+        _chk(x, torch.bfloat16, "x")
+        if dx is not None:                       # dx None: weight + bias gradient only (input gradient: conv_halo_dgrad)
+            _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
     variant = CONV_BWD_VARIANT[layer] if variant is None else variant
     _ck(native.hip().drl_conv_bwd(layer, _p(x), _p(frame_off), frames, _p(dy), _p(w), _p(dw), _p(db), _p(dx),
                                   splits | (variant << 16), ctypes.byref(extra) if extra is not None else None,

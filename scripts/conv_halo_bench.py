@@ -64,6 +64,32 @@ def main():
             print(json.dumps(row), flush=True)
             if out:
                 out.write(json.dumps(row) + "\n")
+    dgrad(out)
+
+
+def dgrad(out):
+    g = torch.Generator().manual_seed(1)
+    wt2 = torch.zeros(4, 32, 2, 2, 64, dtype=torch.bfloat16, device=DEV)
+    wt3 = torch.zeros(64, 3, 3, 64, dtype=torch.bfloat16, device=DEV)
+    w2 = (torch.randn(64, 512, generator=g) * 512 ** -0.5).to(torch.bfloat16).to(DEV)
+    w3 = (torch.randn(64, 576, generator=g) * 576 ** -0.5).to(torch.bfloat16).to(DEV)
+    H.conv_halo_wprep(w2, w3, wt2, wt3)
+    for layer in (2, 3):
+        ishape, oshape, K = SH[layer]
+        for f in (512, 2048, 3072):
+            dy = (torch.randn(f, *oshape, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+            act = torch.relu(torch.randn(f, *ishape, generator=g)).to(torch.bfloat16).to(DEV)
+            dx = torch.zeros_like(act)
+            w, wt = (w2, wt2) if layer == 2 else (w3, wt3)
+            fns = {"halo": lambda: H.conv_halo_dgrad(layer, dy, wt, act, dx, f),
+                   "implicit gemm": lambda: H.conv_dgrad(layer, dy, w, act, dx, f),
+                   "wprep": lambda: H.conv_halo_wprep(w2, w3, wt2, wt3)}
+            t = timeit(fns)
+            flop = 2.0 * f * oshape[0] * oshape[1] * 64 * K
+            row = {"dgrad layer": layer, "frames": f, "us": t, "tflops": {k: round(flop / v / 1e6, 1) for k, v in t.items() if k != "wprep"}}
+            print(json.dumps(row), flush=True)
+            if out:
+                out.write(json.dumps(row) + "\n")
 
 
 if __name__ == "__main__":

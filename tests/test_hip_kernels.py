@@ -601,6 +601,32 @@ def test_conv_dgrad(hip, layer, frames):
     torch.testing.assert_close(dx3.float().cpu(), ref_nomask, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("frames", [1, 2, 33, 512, 1700])
+def test_conv_halo_dgrad(hip, layer, frames):
+    """Input gradient of conv2 / conv3 through the LDS-halo kernel (zero-padded dy, pre-transformed weights, ReLU mask in
+    the epilogue) against fp32 autograd; the frame behind the last one stays untouched."""
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 17 + frames)
+    oh = (hw - ks) // s + 1
+    g = torch.Generator().manual_seed(12)
+    dy = bf(torch.randn(frames, oh, oh, cout, generator=g) * 0.1)
+    xin = xf.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    F.conv2d(xin, w.float().permute(0, 3, 1, 2), None, stride=s).backward(dy.float().permute(0, 3, 1, 2))
+    ref = xin.grad.permute(0, 2, 3, 1) * (xf > 0)
+    _, _, w2, _, _ = _conv_setup(2, 1, 5)
+    _, _, w3, _, _ = _conv_setup(3, 1, 6)
+    ws = {2: w2, 3: w3}
+    ws[layer] = w
+    wt2 = torch.zeros(4, 32, 2, 2, 64, dtype=torch.bfloat16, device=DEV)
+    wt3 = torch.zeros(64, 3, 3, 64, dtype=torch.bfloat16, device=DEV)
+    H.conv_halo_wprep(ws[2].to(DEV), ws[3].to(DEV), wt2, wt3)
+    dx = torch.full((frames + 1, hw, hw, cin), 7.0, dtype=torch.bfloat16, device=DEV)
+    H.conv_halo_dgrad(layer, dy.to(DEV), wt2 if layer == 2 else wt3, x.to(DEV), dx, frames)
+    torch.testing.assert_close(dx[:frames].float().cpu(), ref, rtol=3e-2, atol=3e-2 * float(ref.abs().max()))
+    assert bool((dx[frames] == 7.0).all())
+
+
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("frames,splits,variant", [(3, 1, None), (33, 8, 0), (512, 32, None), (40, 4, 1), (40, 4, 3), (40, 4, 5)])
 def test_conv_bwd_fused(hip, layer, frames, splits, variant):
