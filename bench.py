@@ -175,9 +175,10 @@ def run_rank(args) -> int:
         if os.environ.get("DRL_BENCH_REHEARSAL"):
             extra["rehearsal"] = os.environ["DRL_BENCH_REHEARSAL"]
 
-    # size the shard to the HBM that is actually free (2 M x 56 KB = 113 GB fits an MI355X's 288 GB)
+    # size the shard to the HBM that is actually free: every frame is stored once (replay/device_per.py), ~1.3 planes of
+    # 7 KB per transition -> 2 M transitions = 18 GB (as full stacks: 113 GB)
     free, total = torch.cuda.mem_get_info(dev)
-    per_item = 2 * 28224 + 64
+    per_item = int(1.3 * 7056) + 64
     share = max(1, W // max(1, torch.cuda.device_count())) if os.environ.get("DRL_SHARE_GPU") == "1" else 1
     cap = min(args.replay, int(free * 0.8 // per_item // share))
     cfg = ApexConfig(batch_size=args.batch)
@@ -205,7 +206,8 @@ def run_rank(args) -> int:
     value = updates_s * args.batch * W
     st = eng.stats()                                       # raises if a bounded inter-GPU / inter-workgroup wait timed out
     extra.update({"apex_updates_per_s": updates_s, "loss": st["loss"], "grad_norm": st["grad_norm"],
-                  "replay_items_per_gpu": cap, "graph": eng._graphs[0] if eng._graphs else "eager"})
+                  "replay_items_per_gpu": cap, "replay_gb_per_gpu": round(rep.bytes_per_item() * cap / 1e9, 2),
+                  "graph": eng._graphs[0] if eng._graphs else "eager"})
     if W > 1:
         extra["grad_all_reduce"] = "direct xGMI kernel (in graph)" if dist.xgmi is not None else "process group (%s)" % dist.backend
         if dist.all_reduce_us is not None:                 # stand-alone us per all-reduce of the gradient buffer, both paths
@@ -269,7 +271,7 @@ def run_rank(args) -> int:
             from distributed_rl_amd.replay.device_seq import DeviceSequenceReplay
             rcfg = R2D2Config()
             free, _ = torch.cuda.mem_get_info(dev)
-            scap = min(100_000, int(free * 0.6 // (120 * 28224 + 8192) // share))
+            scap = min(100_000, int(free * 0.6 // (123 * 7056 + 8192) // share))     # T + 3 planes per sequence: 87 GB
             srep = DeviceSequenceReplay(scap, dev, rcfg, seed=dist.rank)
             srep.fill_synthetic(scap, n_action=args.n_action, seed=dist.rank)
             reng = R2D2Engine(args.n_action, rcfg, srep, dev, dist=dist)
@@ -284,6 +286,7 @@ def run_rank(args) -> int:
             extra["r2d2_global_batch"] = rcfg.batch_size * W
             extra["r2d2_vs_paper"] = extra["r2d2_updates_per_s"] / PAPER_R2D2_UPDATES_PER_S
             extra["r2d2_replay_sequences_per_gpu"] = scap
+            extra["r2d2_replay_gb_per_gpu"] = round(srep.frames.numel() / 1e9, 2)
             extra["r2d2_loss"] = rst["loss"]
             extra["r2d2_graph"] = reng._graphs[0] if reng._graphs else "eager"
             s_per, n = steady(dist, reng.step, 20)

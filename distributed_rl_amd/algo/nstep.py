@@ -34,6 +34,8 @@ class NStepBatch(NamedTuple):
     next_state: np.ndarray  # (K, …) uint8
     done: np.ndarray        # (K,) float32
     env: np.ndarray         # (K,) int64 source env id
+    qs: Optional[np.ndarray] = None     # (K,) int64 position of ``state`` in its env's plane stream (vec_assembly.PlaneLog)
+    qs2: Optional[np.ndarray] = None    # (K,) int64 position of ``next_state``
 
 
 class NStepAssembler:

@@ -26,24 +26,122 @@ def _weights(n: int, gamma: float, reference_order: bool) -> np.ndarray:
     return gamma ** (n - 1 - k) if reference_order else gamma ** k
 
 
+class PlaneLog:
+    """Every frame once: the observations of an environment are windows of a PLANE STREAM.
+
+    A frame-stacking environment (wrapped_env.py:30-47) delivers the last ``stack`` frames at every step, so consecutive
+    observations share all but one plane. Per env this log keeps the stream of distinct planes (a ring of the last ``cap``)
+    and the position ``q`` of the current observation in it: observation = planes ``q .. q + stack - 1``. A step that
+    shifts the stack by one appends ONE plane (q += 1); anything else - the first observation, a reset (4 copies of the
+    first frame + no-ops), an env that does not stack at all - appends all ``stack`` planes (q jumps to them). Whether a
+    step shifted is CHECKED on the pixels (the planes that should be shared are compared), never assumed, so any env is
+    stored correctly; one that does not shift just does not compress. The replay stores transitions as two such positions
+    (replay/device_per.py), the wire block carries the planes they span once (transport/codec.py kind 3)."""
+
+    def __init__(self, num_envs: int, cap: int = 512, stack: int = 4):
+        self.E, self.cap, self.stack = num_envs, cap, stack
+        self.P: Optional[np.ndarray] = None                   # [E, cap, H, W]
+        self.head = np.zeros(num_envs, dtype=np.int64)        # planes appended so far, per env
+        self.q = np.zeros(num_envs, dtype=np.int64)           # stream position of the last observation seen
+        self._last: Optional[np.ndarray] = None               # that observation (HWC), to test the next one against
+        self._ar = np.arange(num_envs)
+
+    def _append(self, idx: np.ndarray, planes: np.ndarray) -> None:
+        """planes [len(idx), H, W] -> position head[idx] of each env's ring."""
+        self.P[idx, self.head[idx] % self.cap] = planes
+        self.head[idx] += 1
+
+    def restart(self, obs: np.ndarray, rows: Optional[np.ndarray] = None) -> None:
+        """The observation of envs ``rows`` (default: all) is unrelated to what they showed before (first observation,
+        reset): all its planes enter the stream."""
+        if self.P is None:
+            self.P = np.zeros((self.E, self.cap) + tuple(obs.shape[1:3]), dtype=obs.dtype)
+            self._last = np.zeros_like(obs)
+        rows = self._ar if rows is None else np.asarray(rows)
+        if len(rows) == 0:
+            return
+        self.q[rows] = self.head[rows]
+        for c in range(self.stack):
+            self._append(rows, obs[rows, :, :, c])
+        self._last[rows] = obs[rows]
+
+    def _relation(self, obs: np.ndarray):
+        """Per env: (obs is the last observation again, obs is the last observation moved on by one frame)."""
+        E, k = self.E, self.stack
+        if k == 4 and obs.dtype == np.uint8 and obs.flags.c_contiguous:
+            a = obs.reshape(E, -1).view("<u4")                     # one little-endian word per pixel: byte c = plane c
+            b = self._last.reshape(E, -1).view("<u4")
+            same = (a == b).all(1)
+            rows = np.nonzero(~same)[0]
+            shift = np.zeros(E, dtype=bool)
+            if len(rows):
+                shift[rows] = ((a[rows] & 0x00FFFFFF) == (b[rows] >> 8)).all(1)
+            return same, shift
+        a, b = obs.reshape(E, -1, k), self._last.reshape(E, -1, k)
+        same = (a == b).all((1, 2))
+        return same, ~same & (a[:, :, :k - 1] == b[:, :, 1:]).all((1, 2))
+
+    def observe(self, obs: np.ndarray) -> np.ndarray:
+        """Register the observation [E, H, W, stack] every env shows now - the one seen last again (nothing happens), that
+        one moved on by a frame (one new plane), or something else (all its planes) - and return its stream positions."""
+        if self.P is None:
+            self.restart(obs)
+            return self.q.copy()
+        same, shift = self._relation(obs)
+        i = np.nonzero(shift)[0]
+        if len(i):
+            self._append(i, obs[i, :, :, self.stack - 1])
+            self.q[i] += 1
+            self._last[i] = obs[i]
+        self.restart(obs, np.nonzero(~same & ~shift)[0])
+        return self.q.copy()
+
+    def planes(self, e: int, q0: int, q1: int) -> np.ndarray:
+        """Planes q0 .. q1 (inclusive) of env e."""
+        if self.head[e] - q0 > self.cap or q1 >= self.head[e]:
+            raise IndexError("plane %d..%d of env %d is no longer / not yet in the log (head %d, cap %d)" %
+                             (q0, q1, e, self.head[e], self.cap))
+        return self.P[e, np.arange(q0, q1 + 1) % self.cap]
+
+
+def plane_block(log: PlaneLog, env: np.ndarray, qs: np.ndarray, qs2: np.ndarray):
+    """(planes [M,H,W], win_s [K], win_s2 [K]) of the transitions (env, qs, qs2): per env the planes its transitions span,
+    once; win = index of a window's first plane in the pool."""
+    pools, base = [], 0
+    win_s = np.zeros(len(env), dtype=np.int32)
+    win_s2 = np.zeros(len(env), dtype=np.int32)
+    for e in np.unique(env):
+        m = env == e
+        lo = int(min(qs[m].min(), qs2[m].min()))
+        hi = int(max(qs[m].max(), qs2[m].max())) + log.stack - 1
+        pools.append(log.planes(int(e), lo, hi))
+        win_s[m] = base + (qs[m] - lo)
+        win_s2[m] = base + (qs2[m] - lo)
+        base += hi - lo + 1
+    return np.concatenate(pools), win_s, win_s2
+
+
 class _StepRing:
-    """Last n (state, action, reward) of every env."""
+    """Last n (state, action, reward) of every env (+ the state's position in the env's plane stream, when given)."""
 
     def __init__(self, E: int, n: int):
         self.E, self.n = E, n
         self.S: Optional[np.ndarray] = None
         self.A = np.zeros((n, E), dtype=np.int64)
         self.R = np.zeros((n, E), dtype=np.float64)
+        self.Q = np.zeros((n, E), dtype=np.int64)
         self.cnt = np.zeros(E, dtype=np.int64)
         self.t = 0
 
-    def write(self, state, action, reward) -> int:
+    def write(self, state, action, reward, q=None) -> int:
         if self.S is None:
             self.S = np.zeros((self.n,) + tuple(state.shape), dtype=state.dtype)
         h = self.t % self.n
         self.S[h] = state
         self.A[h] = action
         self.R[h] = reward
+        if q is not None:
+            self.Q[h] = q
         np.minimum(self.cnt + 1, self.n, out=self.cnt)
         self.t += 1
         return h
@@ -61,17 +159,21 @@ class VecNStepAssembler:
         self.ring = _StepRing(num_envs, nstep)
         self.w = _weights(nstep, gamma, reference_order)
 
-    def step(self, state, action, reward, next_state, done) -> Optional[NStepBatch]:
+    def step(self, state, action, reward, next_state, done, q_state=None, q_next=None) -> Optional[NStepBatch]:
+        """q_state / q_next (optional, [E] int64): positions of ``state`` / ``next_state`` in the envs' plane streams
+        (PlaneLog.observe); the emitted batch then carries the positions of its states (``qs``, ``qs2``)."""
         r, n = self.ring, self.n
-        h = r.write(state, action, reward)
+        h = r.write(state, action, reward, q_state)
         done = np.asarray(done, dtype=bool)
         ready = np.nonzero(r.cnt == n)[0]
         old = (h + 1) % n
         parts = []
+        qn = q_next if q_next is not None else np.zeros(self.E, dtype=np.int64)
         if len(ready):
             order = (old + np.arange(n)) % n
             ret = (self.w[:, None] * r.R[order][:, ready]).sum(0)
-            parts.append((r.S[old, ready], r.A[old, ready], ret, next_state[ready], done[ready].astype(np.float32), ready))
+            parts.append((r.S[old, ready], r.A[old, ready], ret, next_state[ready], done[ready].astype(np.float32), ready,
+                          r.Q[old, ready], qn[ready]))
         didx = np.nonzero(done)[0]
         if len(didx):
             if self.flush_tail:                                   # the last n-1 truncated windows end the episode too
@@ -83,13 +185,15 @@ class VecNStepAssembler:
                         k = np.arange(len(tail))
                         w = self.gamma ** (n - 1 - k) if self.reference_order else self.gamma ** k
                         parts.append((r.S[tail[0], e][None], r.A[tail[0], e][None], np.array([(w * r.R[tail, e]).sum()]),
-                                      next_state[e][None], np.ones(1, np.float32), np.array([e])))
+                                      next_state[e][None], np.ones(1, np.float32), np.array([e]), r.Q[tail[0], e][None],
+                                      qn[e][None]))
             r.cnt[didx] = 0
         if not parts:
             return None
         cat = (lambda i: parts[0][i]) if len(parts) == 1 else (lambda i: np.concatenate([p[i] for p in parts]))
+        pos = (cat(6).astype(np.int64), cat(7).astype(np.int64)) if q_state is not None else (None, None)
         return NStepBatch(cat(0), cat(1).astype(np.int64), cat(2).astype(np.float32), cat(3), cat(4).astype(np.float32),
-                          cat(5).astype(np.int64))
+                          cat(5).astype(np.int64), *pos)
 
 
 class VecSequenceAssembler:

@@ -73,7 +73,13 @@ __device__ __forceinline__ uint4 bf16x8_to_f16(bf16x8 v, float& sum) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv1: u8 [*,84,84,4] (dense batch, or frames of a replay store addressed by byte offsets) -> bf16 [n,20,20,32]
+// conv1: u8 frames -> bf16 [n,20,20,32]. Two input forms:
+//   dense (OFF = false):  [n,84,84,4] HWC stacks as the environments deliver them (actors); weights [32][kh][kw][c].
+//   store (OFF = true):   a replay store of single 84x84 PLANES (each frame kept once: replay/device_per.py); frame b =
+//                         the 4 consecutive planes starting at byte offset frame_off[b]; weights [32][c][kh][kw].
+// In both forms the contraction index is k = 32 s + 8 g + j with j = 8 consecutive bytes of the input: dense s = kh, (g, j)
+// = the 8 px x 4 ch of a patch row; store s = 2 c + kh / 4, g = kh % 4, j = kw. The weight fragment address (row * 256 +
+// 32 s + 8 g) is the same expression for both orders; only the input address differs.
 // ---------------------------------------------------------------------------------------------------------------
 // A second network (its own frame offsets / weights / bias / output / row count, same frame store x) may ride along in
 // the same launch: blocks [nblk1, gridDim.x) work on it (Ape-X learner: online net on [s ; s'] + target net on s' as ONE
@@ -171,8 +177,11 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
         const int m = min(min(tile, ntiles - 1) * 16 + r, M - 1);
         b = m / 400;
         const int rem = m - b * 400, oy = rem / 20, ox = rem - oy * 20;
-        return oy * (4 * 336) + ox * 16 + g * 8;
+        if constexpr (OFF) return (4 * oy + g) * 84 + 4 * ox;          // plane store: row 4 oy + kh % 4 of plane c
+        else return oy * (4 * 336) + ox * 16 + g * 8;
     };
+    // byte offset of k-step s relative to locate(): dense = patch row s; store = plane s / 2, patch rows 4 (s % 2) ..
+    auto koff = [](int s) -> int { return OFF ? (s >> 1) * 7056 + (s & 1) * 336 : s * 336; };
     auto frame_base = [&](int b) -> long long {
         if constexpr (OFF) return frame_off[b];
         else return (long long)b * 28224;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
     const long long f0 = frame_base(b0);
     long long fnext = frame_base(b1);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bufa[s] = *reinterpret_cast<const uint2*>(x + f0 + p0 + s * 336);
+    for (int s = 0; s < 8; ++s) bufa[s] = *reinterpret_cast<const uint2*>(x + f0 + p0 + koff(s));
     long long bnext = fnext + p1;
     // one tile: prefetch tile+1 into `nxt`, compute `cur`. Called with the two buffers swapped (no register copies,
     // and the compiler cannot sink the prefetch below the compute because both buffers are live).
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
         const int p2 = locate(tile + 2, b2);
         const long long f2 = frame_base(b2);                                                         // tile + 2 (first)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + s * 336);    // tile + 1
+        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + koff(s));    // tile + 1
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
 #if DRL_CONV1_F16
         f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};

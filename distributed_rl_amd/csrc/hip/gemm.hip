@@ -95,8 +95,10 @@ struct DenseOp {
 
 // Implicit im2col of an NHWC tensor: logical matrix col[M = frames*OH*OW][K = KS*KS*C], K ordered (kh, kw, c).
 // U8 = source is raw uint8 frames (conv1): 8 elements = 8 bytes, widened to bf16 on load (exact for 0..255; the
-// 1/255 lives in the epilogue scale). frame_off (optional) = byte/element offset of each frame: conv1 reads straight
-// out of the replay store through the sampled indices — no gather copy.
+// 1/255 lives in the epilogue scale). OFF_ (conv1 only) = the source is a replay store of single H x W PLANES (every
+// frame kept once, replay/device_per.py): frame b = the C consecutive planes from byte offset frame_off[b], and K is
+// ordered (c, kh, kw) - PyTorch's own weight order - so that 8 consecutive k are still 8 consecutive bytes (one patch
+// row of one plane). conv1 reads straight out of the store through the sampled offsets - no gather copy.
 template <int H_, int W_, int C_, int KS_, int S_, bool U8_, bool OFF_ = false>
 struct ConvOp {
     static constexpr int H = H_, W = W_, C = C_, KS = KS_, S = S_;
@@ -112,9 +114,8 @@ struct ConvOp {
         const int b = mm / (OH * OW), rem = mm - b * (OH * OW);
         const int oy = rem / OW, ox = rem - oy * OW;
         off_t fb;
-        if constexpr (OFF_) fb = frame_off[b];
-        else fb = (off_t)b * (off_t)(H * W * C);
-        return fb + (off_t)(((oy * S) * W + ox * S) * C);
+        if constexpr (OFF_) return (off_t)frame_off[b] + (off_t)((oy * S) * W + ox * S);
+        else return (off_t)b * (off_t)(H * W * C) + (off_t)(((oy * S) * W + ox * S) * C);
     }
     // OFF_: the frame base is a dependent global load (frame_off[b]). When the rows of a tile change every K-tile (TR
     // operand of the weight-gradient GEMM) that load would sit in front of every data load and serialise the prefetch
@@ -129,11 +130,18 @@ struct ConvOp {
         const int mm = m < rows ? m : 0;
         const int b = mm / (OH * OW), rem = mm - b * (OH * OW);
         const int oy = rem / OW, ox = rem - oy * OW;
-        return (off_t)fb + (off_t)(((oy * S) * W + ox * S) * C);
+        if constexpr (OFF_) return (off_t)fb + (off_t)((oy * S) * W + ox * S);
+        else return (off_t)fb + (off_t)(((oy * S) * W + ox * S) * C);
     }
     __device__ __forceinline__ int col_off(int kc) const {
-        int kh = kc / KWC;
-        return kh * (W * C) + (kc - kh * KWC);
+        if constexpr (OFF_) {                     // k = (c, kh, kw): plane c, patch row kh
+            static_assert(!OFF_ || (U8_ && KS_ == 8), "the plane store form is conv1's");
+            const int c = kc / (KS * KS), rem = kc - c * (KS * KS), kh = rem / KS;
+            return c * (H * W) + kh * W + (rem - kh * KS);
+        } else {
+            const int kh = kc / KWC;
+            return kh * (W * C) + (kc - kh * KWC);
+        }
     }
     __device__ __forceinline__ off_t addr(off_t rb, int kc) const { return rb + (off_t)col_off(kc); }
     __device__ __forceinline__ bool pair_ok(off_t, int) const { return true; }
@@ -1076,7 +1084,7 @@ struct TreeBody {
 struct SampleBody {
     typedef SampleArgs Args;
     static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
-        sample_block(g.tr, g.st, g.seed, g.B, g.idx_out, g.prio_out, g.gen, g.gen_out, g.frame_off, g.frame_bytes, g.begin_n_items,
+        sample_block(g.tr, g.st, g.seed, g.B, g.idx_out, g.prio_out, g.gen, g.gen_out, g.frame_off, g.win, g.begin_n_items,
                      g.is_n_scale, block, reinterpret_cast<float*>(smem));
     }
     static int plan(Args& g, const void* extra, size_t* lds) {

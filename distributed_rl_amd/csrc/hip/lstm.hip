@@ -25,12 +25,14 @@ __global__ __launch_bounds__(256) void k_lstm_bwd_point(const bf16_t* __restrict
     *reinterpret_cast<uint2*>(dgates + ((long long)b * H + u) * 4) = dg;
 }
 
-// frame byte offsets of a sampled sequence batch, time-major: off[t*B + b] = (idx[b]*T + t) * frame_bytes
-__global__ void k_seq_offsets(const int* __restrict__ idx, int B, int T, long long frame_bytes, long long* __restrict__ off) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// byte offsets of the plane windows of a sampled sequence batch, time-major: off[t*B + b] = idx[b] * seq_bytes + t *
+// plane_bytes (a sequence slot holds T + 3 single planes: step t is the 4 planes from plane t, replay/device_seq.py)
+__global__ void k_seq_offsets(const int* __restrict__ idx, int B, int T, long long seq_bytes, long long plane_bytes,
+                              long long* __restrict__ off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * T) return;
-    int t = i / B, b = i - t * B;
-    off[i] = ((long long)idx[b] * T + t) * frame_bytes;
+    const int t = i / B, b = i - t * B;
+    off[i] = (long long)idx[b] * seq_bytes + (long long)t * plane_bytes;
 }
 
 // dst[b][:] = src[idx[b]][:]  (f32 rows -> f32 and bf16 copies): stored recurrent state of the sampled sequences
@@ -71,9 +73,9 @@ DRL_API int drl_lstm_bwd_point(const void* dh_head, float* dh_rec, float* dc, co
                                                      (bf16_t*)dgates, n, H);
     return (int)hipGetLastError();
 }
-DRL_API int drl_seq_offsets(const int* idx, int B, int T, long long frame_bytes, long long* off, hipStream_t s) {
+DRL_API int drl_seq_offsets(const int* idx, int B, int T, long long seq_bytes, long long plane_bytes, long long* off, hipStream_t s) {
     if (B <= 0 || T <= 0) return -1;
-    k_seq_offsets<<<(B * T + 255) / 256, 256, 0, s>>>(idx, B, T, frame_bytes, off);
+    k_seq_offsets<<<(B * T + 255) / 256, 256, 0, s>>>(idx, B, T, seq_bytes, plane_bytes, off);
     return (int)hipGetLastError();
 }
 DRL_API int drl_gather_state(const float* src, const int* idx, int B, int H, float* dst_f32, void* dst_bf16, hipStream_t s) {

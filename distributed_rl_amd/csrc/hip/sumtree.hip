@@ -33,10 +33,10 @@ __global__ void k_step_end(StepState* st) {
 __global__ __launch_bounds__(1024) void k_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
                                                int* __restrict__ idx_out, float* __restrict__ prio_out,
                                                const int* __restrict__ gen, int* __restrict__ gen_out,
-                                               long long* __restrict__ frame_off, long long frame_bytes,
+                                               long long* __restrict__ frame_off, const long long* __restrict__ win,
                                                const long long* __restrict__ begin_n_items, float is_n_scale) {
     __shared__ float s_w[16];
-    sample_block(tr, st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, frame_bytes, begin_n_items, is_n_scale, blockIdx.x, s_w);
+    sample_block(tr, st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, win, begin_n_items, is_n_scale, blockIdx.x, s_w);
 }
 
 // Leaves <- new priorities (dropped when the slot generation changed since sampling).
@@ -124,13 +124,13 @@ DRL_API int drl_step_end(void* st, hipStream_t s) {
 
 DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, long long cap, void* st,
                                unsigned long long seed, int B, int* idx_out, float* prio_out, const int* gen,
-                               int* gen_out, long long* frame_off, long long frame_bytes, const long long* begin_n_items,
+                               int* gen_out, long long* frame_off, const long long* win, const long long* begin_n_items,
                                float is_n_scale, hipStream_t s) {
     if (n_levels < 1 || n_levels > MAX_LEVELS || B <= 0) return -1;
     TreeDesc d = make_desc(base, n_levels, off, cap);
     const int wpb = (begin_n_items && is_n_scale > 0.f) ? 16 : 4;           // waves per block (one atomic per block, see kernel)
     k_sample<<<(B + wpb - 1) / wpb, wpb * 64, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off,
-                                                     frame_bytes, begin_n_items, is_n_scale);
+                                                     win, begin_n_items, is_n_scale);
     return (int)hipGetLastError();
 }
 

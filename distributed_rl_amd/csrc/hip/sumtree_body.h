@@ -110,7 +110,7 @@ __device__ __forceinline__ void tree_rebuild_upper_block(const TreeDesc& tr, int
 __device__ __forceinline__ void sample_block(const TreeDesc& tr, StepState* st, unsigned long long seed, int B,
                                              int* __restrict__ idx_out, float* __restrict__ prio_out,
                                              const int* __restrict__ gen, int* __restrict__ gen_out,
-                                             long long* __restrict__ frame_off, long long frame_bytes,
+                                             long long* __restrict__ frame_off, const long long* __restrict__ win,
                                              const long long* __restrict__ begin_n_items, float is_n_scale, int block, float* s_w) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = block * (blockDim.x >> 6) + wave;
@@ -162,9 +162,9 @@ __device__ __forceinline__ void sample_block(const TreeDesc& tr, StepState* st, 
             w_is = __powf((float)(*begin_n_items) * is_n_scale * leaf_p / top_sum, -beta);
         }
         if (gen_out) gen_out[b] = gen ? gen[i] : 0;
-        if (frame_off) {                                   // byte offsets of s and s' in the frame store
-            frame_off[b] = (long long)i * frame_bytes;
-            frame_off[B + b] = ((long long)tr.cap + i) * frame_bytes;
+        if (frame_off) {                                   // byte offsets of the plane windows of s and s' in the frame store
+            frame_off[b] = win[i];                         // (per-slot table written at ingest: replay/device_per.py)
+            frame_off[B + b] = win[tr.cap + i];
         }
     }
     }
@@ -195,7 +195,7 @@ struct SampleExtra {
     const int* gen;
     int* gen_out;
     long long* frame_off;
-    long long frame_bytes;
+    const long long* win;
     const long long* begin_n_items;
     float is_n_scale, pad2;
 };
@@ -211,7 +211,7 @@ struct SampleArgs {           // device-side copy
     const int* gen;
     int* gen_out;
     long long* frame_off;
-    long long frame_bytes;
+    const long long* win;
     const long long* begin_n_items;
     float is_n_scale;
 };
@@ -223,7 +223,7 @@ static inline int fill_sample_args(const void* extra_, SampleArgs* sa) {     // 
     if (e->n_levels < 1 || e->n_levels > MAX_LEVELS || e->B <= 0) return -1;
     sa->tr = make_desc(e->base, e->n_levels, e->off, e->cap);
     sa->st = (StepState*)e->st; sa->seed = e->seed; sa->B = e->B; sa->idx_out = e->idx_out; sa->prio_out = e->prio_out;
-    sa->gen = e->gen; sa->gen_out = e->gen_out; sa->frame_off = e->frame_off; sa->frame_bytes = e->frame_bytes;
+    sa->gen = e->gen; sa->gen_out = e->gen_out; sa->frame_off = e->frame_off; sa->win = e->win;
     sa->begin_n_items = e->begin_n_items; sa->is_n_scale = e->is_n_scale;
     return (e->B + 3) / 4;
 }

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from ..models import DuelingDQN
-from ..models.packing import ParamPack, apex_layout
+from ..models.packing import ParamPack, apex_layout, conv1_hwc
 from ..ops import hip as H
 from .streams import capture_graph
 from ..utils import epsilon_ladder
@@ -39,6 +39,7 @@ class ActorEngine:
             self.Pb = self.P.like(torch.bfloat16)
             H.cast_bf16(self.P.flat, self.Pb.flat)
             self.owns = True
+        self.refresh_conv1()
         self.buf = TorsoBuffers(num_envs, n_action, dev)
         self.obs = torch.zeros(num_envs, 84, 84, 4, dtype=torch.uint8, device=dev)
         self.action = torch.zeros(num_envs, dtype=torch.int32, device=dev)
@@ -56,17 +57,28 @@ class ActorEngine:
         self._k = 0
 
     # ---- parameters -----------------------------------------------------------------------------------
+    def refresh_conv1(self) -> None:
+        """The environments deliver HWC stacks; the flat buffer keeps conv1 in the learner's (c, kh, kw) order (its input is
+        the replay's plane store). The actor's conv1 runs on an HWC-ordered copy, rebuilt whenever the parameters change
+        (shared-parameter actors: call this after the learner moved them)."""
+        w = conv1_hwc(self.Pb.view("conv1.w"))
+        if getattr(self, "w1", None) is None:
+            self.w1 = w
+        else:
+            self.w1.copy_(w)                         # same address: a captured inference graph keeps reading it
+
     def load_flat(self, flat_fp32) -> None:
         """Refresh from a flat fp32 parameter buffer in kernel layout (ParamChannel.pull / broadcast target)."""
         assert self.owns, "shared-parameter actors read the learner's weights directly"
         t = torch.as_tensor(flat_fp32)
         self.P.flat.copy_(t.to(self.device, non_blocking=True))
         H.cast_bf16(self.P.flat, self.Pb.flat)
+        self.refresh_conv1()
 
     # ---- inference --------------------------------------------------------------------------------------
     def _launch(self) -> None:
         H.step_begin(self.st, self._n)               # advances the Philox counter on device
-        torso_forward(self.obs, None, self.E, self.Pb, self.P, self.buf, self.action, self.eps, 0, self.seed, self._ctr)
+        torso_forward(self.obs, None, self.E, self.Pb, self.P, self.buf, self.action, self.eps, 0, self.seed, self._ctr, w1=self.w1)
 
     def infer(self) -> torch.Tensor:
         """Q + ε-greedy actions for the frames currently in ``self.obs``; returns the device action tensor."""
@@ -114,13 +126,38 @@ class ActorEngine:
             self._pprio = torch.zeros(K, device=dev)
         self._pframes[:K].copy_(torch.from_numpy(np.ascontiguousarray(state)), non_blocking=True)
         self._pframes[K:].copy_(torch.from_numpy(np.ascontiguousarray(next_state)), non_blocking=True)
-        torso_forward(self._pframes, None, 2 * K, self.Pb, self.P, self._pbuf)
+        torso_forward(self._pframes, None, 2 * K, self.Pb, self.P, self._pbuf, w1=self.w1)
         a = torch.from_numpy(np.ascontiguousarray(action, dtype=np.int32)).to(dev)
         r = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)).to(dev)
         d = torch.from_numpy(np.ascontiguousarray(done, dtype=np.float32)).to(dev)
         H.apex_td(self._pbuf.q, self._pbuf.q[K:], None, a, r, d, None, self.st, gamma_n, alpha, prio_eps, self._pdq,
                   self._pprio, use_is=False)
         return self._pprio.cpu().numpy()
+
+    def priorities_planes(self, planes: np.ndarray, win_s: np.ndarray, win_s2: np.ndarray, action: np.ndarray,
+                          reward: np.ndarray, done: np.ndarray, gamma_n: float, alpha: float = 0.6,
+                          prio_eps: float = 1e-5) -> np.ndarray:
+        """``priorities`` for a plane-pool block (codec kind 3): the pool goes to the device once (M planes of 7 KB instead of
+        2 K stacks of 28 KB) and conv1 reads the windows in place, as the learner does from its replay."""
+        K, M = int(action.shape[0]), int(planes.shape[0])
+        dev = self.device
+        if getattr(self, "_ppk", (0, 0))[0] != K or self._ppk[1] < M:
+            self._ppk = (K, max(M, 2 * K))
+            self._ppbuf = TorsoBuffers(2 * K, self.A, dev)
+            self._pplanes = torch.zeros(self._ppk[1], 84 * 84, dtype=torch.uint8, device=dev)
+            self._ppoff = torch.zeros(2 * K, dtype=torch.int64, device=dev)
+            self._pdq2 = torch.zeros(K, self.A, device=dev)
+            self._pprio2 = torch.zeros(K, device=dev)
+        self._pplanes[:M].copy_(torch.from_numpy(np.ascontiguousarray(planes).reshape(M, -1)), non_blocking=True)
+        off = np.concatenate([win_s, win_s2]).astype(np.int64) * (84 * 84)
+        self._ppoff.copy_(torch.from_numpy(off), non_blocking=True)
+        torso_forward(self._pplanes, self._ppoff, 2 * K, self.Pb, self.P, self._ppbuf)
+        a = torch.from_numpy(np.ascontiguousarray(action, dtype=np.int32)).to(dev)
+        r = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)).to(dev)
+        d = torch.from_numpy(np.ascontiguousarray(done, dtype=np.float32)).to(dev)
+        H.apex_td(self._ppbuf.q, self._ppbuf.q[K:], None, a, r, d, None, self.st, gamma_n, alpha, prio_eps, self._pdq2,
+                  self._pprio2, use_is=False)
+        return self._pprio2.cpu().numpy()
 
     # ---- benchmarks -------------------------------------------------------------------------------------
     def step_synthetic(self) -> None:

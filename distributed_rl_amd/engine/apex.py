@@ -47,9 +47,12 @@ class TorsoBuffers:
 
 
 def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int, wb: ParamPack, wf: ParamPack,
-                  buf: TorsoBuffers, action_out=None, eps=None, eps_mod: int = 0, seed: int = 0, ctr=None) -> None:
-    """wb = bf16 weights, wf = fp32 params (biases). 5 launches: conv1-3, FC1(+bias+ReLU), head(+dueling[+ε-greedy])."""
-    H.conv_fwd(1, x_u8, wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
+                  buf: TorsoBuffers, action_out=None, eps=None, eps_mod: int = 0, seed: int = 0, ctr=None, w1=None) -> None:
+    """wb = bf16 weights, wf = fp32 params (biases). 5 launches: conv1-3, FC1(+bias+ReLU), head(+dueling[+ε-greedy]).
+    frame_off given: x_u8 is a replay store of single planes and conv1 uses the pack's (c, kh, kw) weights; dense HWC
+    stacks (actors, frame_off None) need ``w1`` = the HWC-ordered copy (models.packing.conv1_hwc)."""
+    assert (frame_off is None) == (w1 is not None), "dense HWC input <-> HWC-ordered conv1 weights"
+    H.conv_fwd(1, x_u8, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
     H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, n)
     H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, n)
     # FC1: 64x64 tiles, LDS-DMA mainloop with 4 stages (variant 10): 17.6 us vs 20.9 us for the register ring at n = 1024

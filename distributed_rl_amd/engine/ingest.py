@@ -2,7 +2,7 @@
 Replay thread of the reference, ape_x/replay.py:24-35, whose drain shares the GIL and a lock with the training loop and
 which the learner has to ``_sleep`` for, ape_x/learner.py:47-49).
 
-Pipeline of one experience block (8 MB of uint8 frames for 148 Ape-X transitions):
+Pipeline of one experience block (plane-pool blocks: ~0.5 MB for 50 Ape-X transitions; 8 MB for 148 as full stacks):
 
   ring slot (shm) --thread: ONE memcpy--> pinned staging buffer --ingest stream: DMA--> replay ring in HBM
                                                                                         |
@@ -37,12 +37,12 @@ from ..transport import codec
 
 
 class _Staged:
-    __slots__ = ("buf", "meta", "fields", "start", "K", "done", "retired_at")
+    __slots__ = ("buf", "meta", "fields", "blk", "K", "done", "retired_at")
 
     def __init__(self, buf, meta, fields):
         self.buf, self.meta, self.fields = buf, meta, fields
         self.K = int(meta["K"])
-        self.start, self.done, self.retired_at = -1, None, -1
+        self.blk, self.done, self.retired_at = None, None, -1
 
 
 class AsyncIngest:
@@ -145,7 +145,7 @@ class AsyncIngest:
         # 3. commit the blocks whose DMA has finished (polled: the learner stream never waits for a copy)
         while self._copying and self._copying[0].done.query():
             rec = self._copying.popleft()
-            r.commit(rec.start, self._prio[rec.buf], rec.K)
+            r.commit_block(rec.blk, self._prio[rec.buf])
             with self._lock:
                 self._free.append(rec.buf)
             n_commit += rec.K
@@ -161,10 +161,7 @@ class AsyncIngest:
                 while self._retired and self._retired[0].retired_at < self._tick - 1:
                     rec = self._retired.popleft()
                     v = self._views(rec)
-                    if rec.meta["kind"] == codec.KIND_APEX:
-                        r.write_slots(rec.start, v["state"], v["next_state"], v["action"], v["reward"], v["done"])
-                    else:
-                        r.write_slots(rec.start, v["frames"], v["action"], v["reward"], v["done"], v["length"], v["h0"], v["c0"])
+                    r.write_views(rec.blk, int(rec.meta["kind"]), v)     # plane pool / stacks / sequences: the replay knows
                     self._prio[rec.buf][:rec.K].copy_(v["prio"], non_blocking=True)
                     rec.done = torch.cuda.Event()
                     rec.done.record(self.stream)
@@ -177,8 +174,8 @@ class AsyncIngest:
                 break
             if rec.K > self._prio[rec.buf].numel():
                 self._prio[rec.buf] = torch.zeros(rec.K, device=self.device)
-            rec.start = r.reserve(rec.K)
-            r.retire(rec.start, rec.K)
+            K, M = r.block_need(int(rec.meta["kind"]), rec.K, int(rec.meta.get("M", 0)))
+            rec.blk = r.reserve_block(K, M)           # ranges of the replay's rings; whatever owned them leaves the tree
             rec.retired_at = self._tick
             self._retired.append(rec)
         return n_commit

@@ -110,7 +110,10 @@ class HipLearner:
         else:
             from ..replay.device_per import DevicePER
             from .apex import ApexEngine
-            self.replay = DevicePER(replay_size, self.device, batch_size=cfg.batch_size, seed=seed)
+            # planes per transition of capacity: ~1.1-1.3 with the actors' plane-pool blocks; 8 if the producers send full
+            # stacks (codec kind 1: DRL_PLANE_BLOCKS=0 actors, external tools)
+            ppi = float(os.environ.get("DRL_PLANES_PER_ITEM", "1.3"))
+            self.replay = DevicePER(replay_size, self.device, batch_size=cfg.batch_size, seed=seed, planes_per_item=ppi)
             self.engine = ApexEngine(n_action, cfg, self.replay, self.device, dist=dist, use_graph=use_graph)
         self.publish_interval = publish_interval
         self.max_blocks = max_blocks_per_step
@@ -132,16 +135,16 @@ class HipLearner:
 
     def _fit_capacity(self, want: int, cfg) -> int:
         """The replay lives in HBM: clamp the requested item count to what fits next to the engine's activations (75 %
-        of the free memory). The reference's default ``-s 100000`` means 100 000 SEQUENCES for R2D2 = 315 GiB of uint8
-        frames; an MI355X holds ~65 000 of them (and ~3.8 M Ape-X transitions)."""
+        of the free memory). With every frame stored once the reference's default ``-s 100000`` - 100 000 SEQUENCES for
+        R2D2 - is 87 GB (full stacks: 315 GiB), and an MI355X holds ~20 M Ape-X transitions."""
         import warnings
         if self.device.type != "cuda":
             return want
         free, _ = torch.cuda.mem_get_info(self.device)
-        if self.is_r2d2:
-            per_item = cfg.total_len * (28224 + 16) + 2 * 4 * cfg.hidden + 64
-        else:
-            per_item = 2 * 28224 + 64
+        if self.is_r2d2:                 # T + 3 single planes per sequence (replay/device_seq.py)
+            per_item = (cfg.total_len + 3) * 7056 + cfg.total_len * 16 + 2 * 4 * cfg.hidden + 64
+        else:                            # ~1.3 planes per transition (replay/device_per.py) + tables
+            per_item = int(float(os.environ.get("DRL_PLANES_PER_ITEM", "1.3")) * 7056) + 64
         fit = int(free * 0.75 // per_item)
         if want > fit:
             warnings.warn("replay size %d does not fit in HBM (%.0f GiB free): using %d" % (want, free / 2 ** 30, fit))

@@ -62,7 +62,7 @@ def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
 
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
                       wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None,
-                      persistent: bool = False, prep=None) -> None:
+                      persistent: bool = False, prep=None, w1=None) -> None:
     """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
     all T) + ONE input-projection GEMM for those steps (throughput-bound). ``persistent``: the recurrence that follows is
     the persistent kernel (it may take over the bias add, see defer_xg_bias)."""
@@ -71,7 +71,10 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     x = frames if frame_off is not None else frames[r0:r1]
     fo = frame_off[r0:r1] if frame_off is not None else None
     a1, a2, a3 = buf.act1[r0:r1], buf.act2[r0:r1], buf.act3[r0:r1]
-    H.conv_fwd(1, x, wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
+    # frame_off given: the frames are plane windows of the replay store, conv1 weights in the pack's (c, kh, kw) order; dense
+    # HWC stacks (the actors' sequence-priority pass) need w1 = the HWC-ordered copy (models.packing.conv1_hwc)
+    assert (frame_off is None) == (w1 is not None), "dense HWC input <-> HWC-ordered conv1 weights"
+    H.conv_fwd(1, x, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
     H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n, prep=prep if t0 == 0 else None)
     H.conv_fwd(3, a2, wb.view("conv3.w"), wf.view("conv3.b"), a3, n)
     if t0 == 0:
@@ -161,11 +164,11 @@ def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack,
 
 
 def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
-                    wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, persistent: bool) -> None:
+                    wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, persistent: bool, w1=None) -> None:
     """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0].
     Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
     sequence-priority pass (dense frames, ``frame_off`` None)."""
-    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum, persistent=persistent)
+    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum, persistent=persistent, w1=w1)
     seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent, bsum=bsum)
 
 

@@ -23,7 +23,7 @@ import torch
 
 from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
-from ..models.packing import ParamPack, r2d2_layout
+from ..models.packing import ParamPack, conv1_hwc, r2d2_layout
 from ..ops import hip as H
 from .streams import capture_graph
 from ..utils import epsilon_ladder
@@ -79,12 +79,23 @@ class R2D2ActorEngine:
     def sync_target(self) -> None:
         self.Tg.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
+        self._refresh_conv1()
 
     def load_flat(self, flat_fp32) -> None:
         t = torch.as_tensor(flat_fp32)
         self.P.flat.copy_(t.to(self.device, non_blocking=True))
         H.cast_bf16(self.P.flat, self.Pb.flat)
         self.sync_target()
+
+    def _refresh_conv1(self) -> None:
+        """HWC-ordered copies of the online / target conv1 weights (the flat buffers keep the learner's (c, kh, kw) order;
+        the environments deliver HWC stacks). Same addresses on every refresh: the captured inference graph reads them."""
+        for name, pack in (("w1", self.Pb), ("w1_tg", self.Tb)):
+            w = conv1_hwc(pack.view("conv1.w"))
+            if getattr(self, name, None) is None:
+                setattr(self, name, w)
+            else:
+                getattr(self, name).copy_(w)
 
     # ---- recurrent state ------------------------------------------------------------------------------
     def get_state(self, rows: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
@@ -111,7 +122,7 @@ class R2D2ActorEngine:
     def _launch(self) -> None:
         E, Hd, wb, wf = self.E, self.Hd, self.Pb, self.P
         H.step_begin(self.st, self._n)               # advances the Philox counter on device
-        H.conv_fwd(1, self.obs, wb.view("conv1.w"), wf.view("conv1.b"), self.act1, E)
+        H.conv_fwd(1, self.obs, self.w1, wf.view("conv1.b"), self.act1, E)
         H.conv_fwd(2, self.act1, wb.view("conv2.w"), wf.view("conv2.b"), self.act2, E)
         H.conv_fwd(3, self.act2, wb.view("conv3.w"), wf.view("conv3.b"), self.act3, E)
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), self.bsum)
@@ -200,8 +211,8 @@ class R2D2ActorEngine:
             buf.hs[0, :K].copy_(t(h0, torch.bfloat16))
             buf.cs[0, :K].copy_(t(c0, torch.float32))
         fr = self._pframes.view(T * Kp, 84, 84, 4)
-        seq_net_forward(fr, None, T, Kp, Hd, self.Pb, self.P, self._pon, self._pbs[0], persistent)
-        seq_net_forward(fr, None, T, Kp, Hd, self.Tb, self.Tg, self._ptg, self._pbs[1], persistent)
+        seq_net_forward(fr, None, T, Kp, Hd, self.Pb, self.P, self._pon, self._pbs[0], persistent, w1=self.w1)
+        seq_net_forward(fr, None, T, Kp, Hd, self.Tb, self.Tg, self._ptg, self._pbs[1], persistent, w1=self.w1_tg)
         H.r2d2_td(self._pon.q.view(T, Kp, A), self._ptg.q.view(T, Kp, A), self._pidx, self._pact, self._prew, self._pdone,
                   self._plen, self._pw, self.st, cfg.burn_in, cfg.nstep, self.done_offset, cfg.gamma_n, cfg.eta,
                   cfg.rescale_eps, self._pdq, self._pprio)

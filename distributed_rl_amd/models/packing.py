@@ -1,7 +1,9 @@
 """Flat parameter buffers in *kernel layout*  ⇄  reference-shaped ``state_dict``.
 
-The gfx950 kernels want NHWC activations, so weights are stored ``[C_out][kh][kw][C_in]``
-(implicit-GEMM K order), the two 3136→512 heads are concatenated into one 1024-row GEMM
+The gfx950 kernels want NHWC activations, so the conv2 / conv3 weights are stored ``[C_out][kh][kw][C_in]``
+(implicit-GEMM K order); conv1 reads single uint8 planes of the replay store (every frame kept once) and keeps
+PyTorch's own ``[C_out][C_in][kh][kw]`` order (K = plane, patch row, pixel: csrc/hip/conv_direct.hip); the actors,
+whose environments deliver HWC stacks, keep an HWC-ordered copy (``conv1_hwc``). The two 3136→512 heads are concatenated into one 1024-row GEMM
  and every matrix that consumes the flattened conv3 output has its columns
 permuted from the reference's NCHW flatten order (models.py:24) to HWC. One flat fp32 buffer
 holds all parameters back to back (16-byte aligned segments) so that:
@@ -59,6 +61,11 @@ def _conv_from_kernel(w: torch.Tensor) -> torch.Tensor:    # (O,kh,kw,I) → (O,
     return w.permute(0, 3, 1, 2).contiguous()
 
 
+def conv1_hwc(w: torch.Tensor) -> torch.Tensor:
+    """conv1 weights of a flat buffer, (O, I, kh, kw) -> (O, kh, kw, I): the K order of conv1 over dense HWC stacks (actors)."""
+    return w.reshape(32, -1, 8, 8).permute(0, 2, 3, 1).contiguous()
+
+
 def _gate_interleave(w: torch.Tensor, H: int) -> torch.Tensor:
     """PyTorch LSTM row order [i(H); f(H); g(H); o(H)] -> kernel order n = 4*unit + gate, so one lane of the MFMA
     accumulator (4 consecutive columns) holds all four gates of a unit (csrc/hip/gemm.hip EPI_LSTM)."""
@@ -92,7 +99,7 @@ def apex_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
     fh, fw = feat_hw
     F = fh * fw * 64
     segs = [
-        Segment("conv1.w", (32, 8, 8, in_ch)), Segment("conv1.b", (32,)),
+        Segment("conv1.w", (32, in_ch, 8, 8)), Segment("conv1.b", (32,)),
         Segment("conv2.w", (64, 4, 4, 32)), Segment("conv2.b", (64,)),
         Segment("conv3.w", (64, 3, 3, 64)), Segment("conv3.b", (64,)),
         Segment("fc1.w", (1024, F)), Segment("fc1.b", (1024,)),      # rows 0..511 adv1, 512..1023 val1
@@ -102,7 +109,7 @@ def apex_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
 
     def pack(sd):
         return {
-            "conv1.w": _conv_to_kernel(sd["conv1.weight"]), "conv1.b": sd["conv1.bias"],
+            "conv1.w": sd["conv1.weight"], "conv1.b": sd["conv1.bias"],
             "conv2.w": _conv_to_kernel(sd["conv2.weight"]), "conv2.b": sd["conv2.bias"],
             "conv3.w": _conv_to_kernel(sd["conv3.weight"]), "conv3.b": sd["conv3.bias"],
             "fc1.w": _chw_cols_to_hwc(torch.cat([sd["adv1.weight"], sd["val1.weight"]], 0), 64, fh, fw),
@@ -114,7 +121,7 @@ def apex_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
     def unpack(k):
         fc1 = _hwc_cols_to_chw(k["fc1.w"], 64, fh, fw)
         return OrderedDict([
-            ("conv1.weight", _conv_from_kernel(k["conv1.w"])), ("conv1.bias", k["conv1.b"].clone()),
+            ("conv1.weight", k["conv1.w"].clone()), ("conv1.bias", k["conv1.b"].clone()),
             ("conv2.weight", _conv_from_kernel(k["conv2.w"])), ("conv2.bias", k["conv2.b"].clone()),
             ("conv3.weight", _conv_from_kernel(k["conv3.w"])), ("conv3.bias", k["conv3.b"].clone()),
             ("adv1.weight", fc1[:512].contiguous()), ("adv1.bias", k["fc1.b"][:512].clone()),
@@ -131,7 +138,7 @@ def r2d2_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
     F = fh * fw * 64
     H = hidden
     segs = [
-        Segment("conv1.w", (32, 8, 8, in_ch)), Segment("conv1.b", (32,)),
+        Segment("conv1.w", (32, in_ch, 8, 8)), Segment("conv1.b", (32,)),
         Segment("conv2.w", (64, 4, 4, 32)), Segment("conv2.b", (64,)),
         Segment("conv3.w", (64, 3, 3, 64)), Segment("conv3.b", (64,)),
         Segment("lstm.w_ih", (4 * H, F)), Segment("lstm.w_hh", (4 * H, H)),
@@ -143,7 +150,7 @@ def r2d2_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
 
     def pack(sd):
         return {
-            "conv1.w": _conv_to_kernel(sd["conv1.weight"]), "conv1.b": sd["conv1.bias"],
+            "conv1.w": sd["conv1.weight"], "conv1.b": sd["conv1.bias"],
             "conv2.w": _conv_to_kernel(sd["conv2.weight"]), "conv2.b": sd["conv2.bias"],
             "conv3.w": _conv_to_kernel(sd["conv3.weight"]), "conv3.b": sd["conv3.bias"],
             "lstm.w_ih": _gate_interleave(_chw_cols_to_hwc(sd["lstm.weight_ih"], 64, fh, fw), H),
@@ -156,7 +163,7 @@ def r2d2_layout(n_action: int, in_ch: int = 4, feat_hw: Tuple[int, int] = (7, 7)
 
     def unpack(k):
         return OrderedDict([
-            ("conv1.weight", _conv_from_kernel(k["conv1.w"])), ("conv1.bias", k["conv1.b"].clone()),
+            ("conv1.weight", k["conv1.w"].clone()), ("conv1.bias", k["conv1.b"].clone()),
             ("conv2.weight", _conv_from_kernel(k["conv2.w"])), ("conv2.bias", k["conv2.b"].clone()),
             ("conv3.weight", _conv_from_kernel(k["conv3.w"])), ("conv3.bias", k["conv3.b"].clone()),
             ("lstm.weight_ih", _hwc_cols_to_chw(_gate_deinterleave(k["lstm.w_ih"], H), 64, fh, fw).contiguous()),

@@ -8,7 +8,7 @@ SIGS = {
     # sumtree.hip
     "drl_step_begin": [P, P, P],
     "drl_step_end": [P, P],
-    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, L, P, F, P],
+    "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, P, P, F, P],
     "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P, P],
     "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P, L, P],
     "drl_gather_rows": [P, P, P, I, I, P],
@@ -55,7 +55,7 @@ SIGS = {
     # lstm.hip
     "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
     "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
-    "drl_seq_offsets": [P, I, I, L, P, P],
+    "drl_seq_offsets": [P, I, I, L, L, P, P],
     "drl_gather_state": [P, P, I, I, P, P, P],
     "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P],
     "drl_add2": [P, P, P, I, P],

@@ -100,19 +100,21 @@ class TreeLayout:
 
 def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
                    prio_out: torch.Tensor, gen: Optional[torch.Tensor] = None, gen_out: Optional[torch.Tensor] = None,
-                   frame_off: Optional[torch.Tensor] = None, frame_bytes: int = 0,
+                   frame_off: Optional[torch.Tensor] = None, win: Optional[torch.Tensor] = None,
                    begin_n_items: Optional[torch.Tensor] = None, is_n_scale: float = 0.0) -> None:
-    """``begin_n_items`` (int64 device scalar) fuses step_begin into the sampling kernel: beta / n_items of the step
+    """``frame_off`` (int64 [2B]) receives the byte offsets of the plane windows of s and s' of every draw, looked up in
+    ``win`` (int64 [2 cap]: s in the first half, s' in the second; written at ingest).
+    ``begin_n_items`` (int64 device scalar) fuses step_begin into the sampling kernel: beta / n_items of the step
     state are refreshed and the Philox counter of step t is rng_ctr + t + 1 (do not also call step_begin then).
     ``is_n_scale`` > 0 (with begin_n_items) additionally accumulates the batch's max un-normalised IS weight
     (is_n_scale * N * p / total)^-beta in the step state and clears its loss, as ``apex_td_dh`` expects."""
     B = idx_out.numel()
     _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
     if frame_off is not None:
-        _chk(frame_off, torch.int64, "frame_off")
-        assert frame_off.numel() >= 2 * B
+        _chk(frame_off, torch.int64, "frame_off"); _chk(win, torch.int64, "win")
+        assert frame_off.numel() >= 2 * B and win.numel() == 2 * lay.capacity
     _ck(native.hip().drl_sumtree_sample(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(st), seed, B, _p(idx_out),
-                                        _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), frame_bytes, _p(begin_n_items),
+                                        _p(prio_out), _p(gen), _p(gen_out), _p(frame_off), _p(win), _p(begin_n_items),
                                         float(is_n_scale), _s()), "sumtree_sample")
 
 
@@ -542,12 +544,12 @@ class SampleExtra(ctypes.Structure):
                 ("off", ctypes.c_longlong * 6), ("cap", ctypes.c_longlong), ("st", ctypes.c_void_p),
                 ("seed", ctypes.c_ulonglong), ("B", ctypes.c_int), ("pad", ctypes.c_int), ("idx_out", ctypes.c_void_p),
                 ("prio_out", ctypes.c_void_p), ("gen", ctypes.c_void_p), ("gen_out", ctypes.c_void_p),
-                ("frame_off", ctypes.c_void_p), ("frame_bytes", ctypes.c_longlong), ("begin_n_items", ctypes.c_void_p),
+                ("frame_off", ctypes.c_void_p), ("win", ctypes.c_void_p), ("begin_n_items", ctypes.c_void_p),
                 ("is_n_scale", ctypes.c_float), ("pad2", ctypes.c_float)]
 
 
 def sample_extra(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor,
-                 prio_out: torch.Tensor, gen, gen_out, frame_off, frame_bytes: int, begin_n_items: torch.Tensor,
+                 prio_out: torch.Tensor, gen, gen_out, frame_off, win: torch.Tensor, begin_n_items: torch.Tensor,
                  is_n_scale: float) -> SampleExtra:
     """Arguments of ``sumtree_sample(..., begin_n_items=..., is_n_scale=...)`` as a record for ``conv_bwd(1, ..., sample=...)``."""
     _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
@@ -560,7 +562,8 @@ def sample_extra(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: in
     e.gen = gen.data_ptr() if gen is not None else None
     e.gen_out = gen_out.data_ptr() if gen_out is not None else None
     e.frame_off = frame_off.data_ptr() if frame_off is not None else None
-    e.frame_bytes, e.begin_n_items, e.is_n_scale = int(frame_bytes), begin_n_items.data_ptr(), float(is_n_scale)
+    _chk(win, torch.int64, "win"); assert win.numel() == 2 * lay.capacity
+    e.win, e.begin_n_items, e.is_n_scale = win.data_ptr(), begin_n_items.data_ptr(), float(is_n_scale)
     return e
 
 
@@ -790,10 +793,11 @@ def lstm_bwd_step(dh_head, dh_rec_in, dh_rec_out, dh_rec_zero, dc_in, dc_out, ga
                                        _p(gates), _p(c_t), _p(c_prev), _p(dgates), _p(w_hh), B, Hd, _s()), "lstm_bwd_step")
 
 
-def seq_offsets(idx, T: int, frame_bytes: int, off) -> None:
+def seq_offsets(idx, T: int, seq_bytes: int, plane_bytes: int, off) -> None:
+    """off[t * B + b] = idx[b] * seq_bytes + t * plane_bytes: plane-window offsets of a sampled sequence batch, time-major."""
     _chk(idx, torch.int32, "idx"); _chk(off, torch.int64, "off")
     assert off.numel() >= idx.numel() * T
-    _ck(native.hip().drl_seq_offsets(_p(idx), idx.numel(), T, frame_bytes, _p(off), _s()), "seq_offsets")
+    _ck(native.hip().drl_seq_offsets(_p(idx), idx.numel(), T, seq_bytes, plane_bytes, _p(off), _s()), "seq_offsets")
 
 
 def gather_state(src, idx, dst_f32=None, dst_bf16=None) -> None:

@@ -1,51 +1,81 @@
 """HBM-resident prioritized replay for transitions (replaces PrioritizedMemory + Replay thread,
 libs/replay_memory.py:51-81, ape_x/replay.py).
 
-Everything lives in device memory, sized for the 288 GB of an MI355X:
+Every 84x84 frame is stored ONCE: the store is a ring of single uint8 PLANES, and a transition is two
+window starts into it - s = the 4 consecutive planes from ``win[i]``, s' = the 4 from ``win[cap + i]`` (byte offsets).
+An actor ships the planes of a run of consecutive steps of one environment once (transport/codec.py kind 3); inside such
+a run s_t and s_{t+1} share 3 planes and s'_t = s_{t+n}, so a transition costs ~1.1-1.3 planes = 8-9 KB instead of the 56
+KB of two full stacks: 2 M transitions fit in ~18 GB instead of 113 GB. Episode starts need nothing special: the
+environment's reset stack (4 copies of the first frame, wrapped_env.py:32-33) is simply 3 extra planes in the pool.
+conv1 reads its operand straight out of this store through the sampled window offsets (csrc/hip/conv_direct.hip, the
+``OFF`` forms) - a sampled batch is never gathered or copied.
 
-* ``frames``  uint8 ``[2·cap, 84·84·4]`` — states in the first half, next-states in the second (2 M transitions =
-  113 GB; the reference's float32 pickles would need 452 GB). HWC layout, so conv1's implicit-GEMM
-  reads 32 contiguous bytes per kernel row straight out of this store through the sampled byte offsets — a
-  sampled batch is never gathered or copied.
-* ``act / rew / done`` per slot, ``gen`` per-slot generation, and the 64-ary sum-tree.
+Two rings advance together, both FIFO: transition slots (``act / rew / done / win / gen`` + the 64-ary sum-tree) and
+planes. A block is written to contiguous ranges of both (a range that does not fit before the end of a ring starts at 0
+again). Before a range of planes or slots is overwritten, every older block that still owns part of it is RETIRED as a
+whole: its slots leave the tree (priority 0, generation bumped), so nothing samples a transition whose planes are gone.
+The reference evicts FIFO too (``remove_to_fit``, replay_memory.py:70-75), every 100 steps instead of immediately:
+documented deviation, SURVEY §7.3. ``sample`` and ``update`` are pure kernel launches on the current stream with
+preallocated outputs, so they can sit inside a captured hipGraph; the number of live items is a device scalar for the same
+reason.
 
-It is a ring: ingest overwrites the oldest slots (FIFO, like ``remove_to_fit`` — replay_memory.py:70-75 — but
-immediate instead of every 100 steps: documented deviation). ``sample`` and ``update`` are pure
-kernel launches on the current stream with preallocated outputs, so they can sit inside a captured hipGraph;
-the number of live items is a device scalar for the same reason.
+Blocks of kind 1 (full HWC stacks per transition, no plane sharing: the scalar actors, Redis tools) are accepted as well
+and split into 8 planes per transition on the device.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from collections import deque
+from typing import Deque, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from ..ops import hip as H
 
-FRAME_BYTES = 84 * 84 * 4
+PLANE_BYTES = 84 * 84
+STACK = 4
+FRAME_BYTES = PLANE_BYTES * STACK        # one stacked observation as the environments deliver it (HWC)
+
+
+class _Block:
+    """One ingested block: the contiguous slot and plane ranges it owns. state: 0 = reserved (its data may still be on
+    the way: engine/ingest.py keeps several blocks in flight), 1 = committed (in the tree), 2 = evicted before its commit
+    (a replay smaller than what is in flight): the commit is then dropped."""
+    __slots__ = ("slot", "K", "plane", "M", "state")
+
+    def __init__(self, slot: int, K: int, plane: int, M: int):
+        self.slot, self.K, self.plane, self.M, self.state = slot, K, plane, M, 0
+
+
+def _overlap(a0: int, a1: int, b0: int, b1: int) -> bool:
+    return a0 < b1 and b0 < a1
 
 
 class DevicePER:
     def __init__(self, capacity: int, device="cuda", batch_size: int = 512, seed: int = 0,
-                 frame_bytes: int = FRAME_BYTES, max_ingest: int = 4096):
+                 planes_per_item: float = 1.3, plane_capacity: Optional[int] = None, max_ingest: int = 4096):
         self.capacity = int(capacity)
         self.device = torch.device(device)
-        self.frame_bytes = frame_bytes
         self.batch_size = batch_size
         self.seed = seed
+        # planes: 1 per transition inside a run + (n + 3) per run boundary; 8 per transition for kind-1 blocks
+        self.plane_capacity = int(plane_capacity if plane_capacity is not None else self.capacity * planes_per_item + 4 * STACK)
+        self.plane_bytes = PLANE_BYTES
         self.lay = H.TreeLayout(self.capacity)
         dev = self.device
         self.tree = torch.zeros(self.lay.total, device=dev)
         self.gen = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
-        self.frames = torch.zeros(2 * self.capacity, frame_bytes, dtype=torch.uint8, device=dev)
+        self.frames = torch.zeros(self.plane_capacity, PLANE_BYTES, dtype=torch.uint8, device=dev)     # the plane ring
+        self.win = torch.zeros(2 * self.capacity, dtype=torch.int64, device=dev)       # byte offsets: s | s'
         self.act = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
         self.rew = torch.zeros(self.capacity, device=dev)
         self.done = torch.zeros(self.capacity, device=dev)
         self.n_items = torch.zeros(1, dtype=torch.int64, device=dev)
         self._scratch = torch.zeros(max(max_ingest, 64), dtype=torch.int32, device=dev)
-        self.cursor = 0
-        self.count = 0
+        self.cursor = 0              # next transition slot
+        self.pcursor = 0             # next plane
+        self.count = 0               # live transitions (host view; n_items is the device copy)
+        self._blocks: Deque[_Block] = deque()
         # sample outputs (fixed addresses: graph-capturable)
         B = batch_size
         self.idx = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -57,7 +87,7 @@ class DevicePER:
         return self.count
 
     def with_batch(self, batch_size: int) -> "DevicePER":
-        """A second sampler over the SAME store (frames, tree, generations are shared, the sample buffers are its own):
+        """A second sampler over the SAME store (planes, tree, generations are shared, the sample buffers are its own):
         e.g. the strong-scaling measurement of bench.py draws 512 / world per rank from the shard the weak-scaling run
         filled. Ingest through either object, not both."""
         import copy
@@ -75,75 +105,159 @@ class DevicePER:
         top = self.lay.offsets[-1]
         return float(self.tree[top:top + 64].sum())
 
+    def bytes_per_item(self) -> float:
+        """HBM bytes per transition of capacity (planes + tables + tree leaves)."""
+        return (self.frames.numel() + self.win.numel() * 8 + self.capacity * 20) / self.capacity
+
     # ---- ingest -----------------------------------------------------------------------------------
     # Three stages, so that the bulk copy can run on its own stream while the learner keeps stepping (engine/ingest.py):
-    # reserve + retire (the slots leave the tree: nothing samples them any more), write_slots (the data, any stream),
-    # commit (priorities + generation + item count, one launch). ``ingest`` runs the three back to back on one stream.
-    def _ring_write(self, dst: torch.Tensor, src: torch.Tensor, start: int) -> None:
-        n = src.shape[0]
-        first = min(n, self.capacity - start)
-        dst[start:start + first].copy_(src[:first], non_blocking=True)       # pinned source: one DMA straight into the ring
-        if first < n:
-            dst[:n - first].copy_(src[first:], non_blocking=True)
+    # reserve_block (ranges of both rings; everything that still owns part of them leaves the tree: nothing samples it any
+    # more), write_block (the data, any stream), commit_block (priorities + generation + item count, one launch).
+    def _retire(self, slot: int, K: int) -> None:
+        H.sumtree_ingest(self.tree, self.lay, slot, None, self.gen, self._scratch, n=K)
 
-    def reserve(self, K: int) -> int:
-        if K > self.capacity:
+    def reserve_block(self, K: int, M: int) -> _Block:
+        if K > self.capacity or M > self.plane_capacity:
             raise ValueError("block larger than the replay")
         if K > self._scratch.numel():
             self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
-        s = self.cursor
-        self.cursor = (s + K) % self.capacity
-        return s
+        # contiguous ranges: a range that does not fit before the end of its ring starts over at 0, and the skipped tail
+        # counts as overwritten too - both rings then stay in ingestion order, so the blocks in the way are always the
+        # OLDEST ones (front of the deque)
+        slot = self.cursor if self.cursor + K <= self.capacity else 0
+        plane = self.pcursor if self.pcursor + M <= self.plane_capacity else 0
+        s_rng = [(slot, slot + K)] + ([(self.cursor, self.capacity)] if slot != self.cursor else [])
+        p_rng = [(plane, plane + M)] + ([(self.pcursor, self.plane_capacity)] if plane != self.pcursor else [])
 
-    def retire(self, start: int, K: int) -> None:
-        H.sumtree_ingest(self.tree, self.lay, start, None, self.gen, self._scratch, n=K)
+        def in_the_way(b: _Block) -> bool:
+            return any(_overlap(b.slot, b.slot + b.K, lo, hi) for lo, hi in s_rng) or \
+                any(_overlap(b.plane, b.plane + b.M, lo, hi) for lo, hi in p_rng)
 
-    def write_slots(self, start: int, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor,
+        while self._blocks and in_the_way(self._blocks[0]):
+            b = self._blocks.popleft()
+            if b.state == 1:
+                self._retire(b.slot, b.K)                         # FIFO eviction, whole blocks
+                self.count -= b.K
+            b.state = 2
+        if slot != self.cursor or plane != self.pcursor:          # once per lap: the order argument, checked
+            assert not any(in_the_way(b) for b in self._blocks), "replay rings out of ingestion order"
+        self.cursor, self.pcursor = slot + K, plane + M
+        blk = _Block(slot, K, plane, M)
+        self._blocks.append(blk)                                  # owner of its ranges from now on
+        return blk
+
+    def write_block(self, blk: _Block, planes: torch.Tensor, win_s: torch.Tensor, win_s2: torch.Tensor, action: torch.Tensor,
                     reward: torch.Tensor, done: torch.Tensor) -> None:
-        K = int(action.shape[0])
-        self._ring_write(self.frames[:self.capacity], state.reshape(K, -1), start)
-        self._ring_write(self.frames[self.capacity:], next_state.reshape(K, -1), start)
-        self._ring_write(self.act, action, start)
-        self._ring_write(self.rew, reward, start)
-        self._ring_write(self.done, done, start)
+        """planes u8 [M, 84*84] (or [M,84,84]); win_s / win_s2 int32 [K]: plane index, relative to the block's planes, of the
+        first of the 4 consecutive planes of s / s'. Tensors on any device (pinned host memory: one DMA each)."""
+        s, K, p, M = blk.slot, blk.K, blk.plane, blk.M
+        dev = self.device
+        self.frames[p:p + M].copy_(planes.reshape(M, PLANE_BYTES), non_blocking=True)
+        ws = win_s.to(dev, non_blocking=True).to(torch.int64)
+        ws2 = win_s2.to(dev, non_blocking=True).to(torch.int64)
+        self.win[s:s + K] = (ws + p) * PLANE_BYTES
+        self.win[self.capacity + s:self.capacity + s + K] = (ws2 + p) * PLANE_BYTES
+        self.act[s:s + K].copy_(action, non_blocking=True)
+        self.rew[s:s + K].copy_(reward, non_blocking=True)
+        self.done[s:s + K].copy_(done, non_blocking=True)
 
-    def commit(self, start: int, prio: torch.Tensor, K: int) -> None:
+    def write_block_stacks(self, blk: _Block, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor,
+                           reward: torch.Tensor, done: torch.Tensor) -> None:
+        """A kind-1 block: full HWC stacks [K,84,84,4] per transition, no sharing -> 8 planes per transition."""
+        K, p = blk.K, blk.plane
+        assert blk.M == 2 * STACK * K
+        dev = self.device
+        both = torch.stack([state.reshape(K, 84, 84, STACK).to(dev, non_blocking=True),
+                            next_state.reshape(K, 84, 84, STACK).to(dev, non_blocking=True)], 1)      # [K, 2, 84, 84, 4]
+        self.frames[p:p + blk.M].view(K, 2, STACK, 84, 84).copy_(both.permute(0, 1, 4, 2, 3))
+        base = torch.arange(K, device=dev, dtype=torch.int64) * (2 * STACK)
+        s = blk.slot
+        self.win[s:s + K] = (base + p) * PLANE_BYTES
+        self.win[self.capacity + s:self.capacity + s + K] = (base + STACK + p) * PLANE_BYTES
+        self.act[s:s + K].copy_(action, non_blocking=True)
+        self.rew[s:s + K].copy_(reward, non_blocking=True)
+        self.done[s:s + K].copy_(done, non_blocking=True)
+
+    def commit_block(self, blk: _Block, prio: torch.Tensor) -> None:
         """``prio``: float32 on the device, at least K elements. The item count rides along with the tree launch."""
-        self.count = min(self.capacity, self.count + K)
-        H.sumtree_ingest(self.tree, self.lay, start, prio, self.gen, self._scratch, n=K, n_items=self.n_items,
+        if blk.state == 2:                  # its ranges were handed to a younger block while this one was in flight
+            return
+        blk.state = 1
+        self.count += blk.K
+        H.sumtree_ingest(self.tree, self.lay, blk.slot, prio, self.gen, self._scratch, n=blk.K, n_items=self.n_items,
                          n_items_val=self.count)
+
+    # block-kind dispatch used by engine/ingest.py (views of one staged block) and ingest_block (decoded arrays)
+    @staticmethod
+    def block_need(kind: int, K: int, M: int = 0) -> Tuple[int, int]:
+        from ..transport import codec
+        return (K, M) if kind == codec.KIND_APEX_PLANES else (K, 2 * STACK * K)
+
+    def write_views(self, blk: _Block, kind: int, v) -> None:
+        from ..transport import codec
+        if kind == codec.KIND_APEX_PLANES:
+            self.write_block(blk, v["planes"], v["win_s"], v["win_s2"], v["action"], v["reward"], v["done"])
+        else:
+            self.write_block_stacks(blk, v["state"], v["next_state"], v["action"], v["reward"], v["done"])
+
+    def ingest_planes(self, planes, win_s, win_s2, action, reward, done, prio) -> int:
+        K, M = int(action.shape[0]), int(planes.shape[0])
+        if K == 0:
+            return 0
+        blk = self.reserve_block(K, M)
+        self.write_block(blk, planes, win_s, win_s2, action, reward, done)
+        self.commit_block(blk, prio.to(self.device, torch.float32).contiguous())
+        return K
 
     def ingest(self, state: torch.Tensor, next_state: torch.Tensor, action: torch.Tensor, reward: torch.Tensor,
                done: torch.Tensor, prio: torch.Tensor) -> int:
-        """Append K transitions (tensors on any device; frames uint8 HWC, flattened or not)."""
+        """Append K transitions given as full stacks (tensors on any device; frames uint8 HWC, flattened or not)."""
         K = int(action.shape[0])
         if K == 0:
             return 0
-        s = self.reserve(K)
-        self.write_slots(s, state, next_state, action, reward, done)
-        self.commit(s, prio.to(self.device, torch.float32).contiguous(), K)
+        blk = self.reserve_block(K, 2 * STACK * K)
+        self.write_block_stacks(blk, state, next_state, action, reward, done)
+        self.commit_block(blk, prio.to(self.device, torch.float32).contiguous())
         return K
 
     def ingest_block(self, block: Dict[str, np.ndarray]) -> int:
-        """Consume a decoded experience block (transport/codec.py KIND_APEX)."""
-        t = torch.from_numpy
-        return self.ingest(t(np.ascontiguousarray(block["state"])), t(np.ascontiguousarray(block["next_state"])),
-                           t(np.ascontiguousarray(block["action"])), t(np.ascontiguousarray(block["reward"])),
-                           t(np.ascontiguousarray(block["done"])), t(np.ascontiguousarray(block["prio"])))
+        """Consume a decoded experience block (transport/codec.py kind 1 or 3)."""
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(block[k]))  # noqa: E731
+        if "planes" in block:
+            return self.ingest_planes(t("planes"), t("win_s"), t("win_s2"), t("action"), t("reward"), t("done"), t("prio"))
+        return self.ingest(t("state"), t("next_state"), t("action"), t("reward"), t("done"), t("prio"))
 
-    def fill_synthetic(self, n: Optional[int] = None, n_action: int = 4, chunk: int = 65536, seed: int = 0) -> None:
-        """Fill with random Atari-shaped transitions generated ON DEVICE (benchmarks: no dataset, no H2D)."""
+    def fill_synthetic(self, n: Optional[int] = None, n_action: int = 4, chunk: int = 65536, seed: int = 0, nstep: int = 3,
+                       run: int = 64) -> None:
+        """Fill with random Atari-shaped transitions generated ON DEVICE (benchmarks: no dataset, no H2D), shaped like the
+        vectorised actors' blocks: runs of ``run`` consecutive steps of one environment, s' = the stack ``nstep`` steps on."""
         n = self.capacity if n is None else n
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        done = 0
-        while done < n:
-            k = min(chunk, n - done)
-            fr = torch.randint(0, 256, (2, k, self.frame_bytes), dtype=torch.uint8, device=self.device, generator=g)
-            self.ingest(fr[0], fr[1], torch.randint(0, n_action, (k,), device=self.device, generator=g),
-                        torch.randn(k, device=self.device, generator=g).clamp_(-1, 1),
-                        (torch.rand(k, device=self.device, generator=g) < 0.01).float(),
-                        torch.rand(k, device=self.device, generator=g) + 0.1)
-            done += k
+        dev = self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        done_n = 0
+        while done_n < n:
+            k = min(chunk, n - done_n)
+            runs = (k + run - 1) // run
+            per = run + nstep + STACK - 1                                   # planes of one run
+            planes = torch.randint(0, 256, (runs * per, PLANE_BYTES), dtype=torch.uint8, device=dev, generator=g)
+            i = torch.arange(k, device=dev)
+            ws = ((i // run) * per + i % run).to(torch.int32)
+            self.ingest_planes(planes, ws, ws + nstep, torch.randint(0, n_action, (k,), device=dev, generator=g).to(torch.int32),
+                               torch.randn(k, device=dev, generator=g).clamp_(-1, 1),
+                               (torch.rand(k, device=dev, generator=g) < 0.01).float(),
+                               torch.rand(k, device=dev, generator=g) + 0.1)
+            done_n += k
+
+    def gather_stacks(self, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(s, s') of the slots ``idx`` as HWC stacks [n,84,84,4] (tests / tools: the kernels never materialise them)."""
+        out = []
+        flat = self.frames.view(-1)
+        ar = torch.arange(FRAME_BYTES, device=self.device)
+        for half in (0, self.capacity):
+            off = self.win[idx.long() + half]
+            st = flat[(off[:, None] + ar[None, :])].view(-1, STACK, 84, 84)
+            out.append(st.permute(0, 2, 3, 1).contiguous())
+        return out[0], out[1]
 
     # ---- sample / update (graph-capturable) -----------------------------------------------------
     def sample(self, st: torch.Tensor, begin: bool = False, is_n_scale: float = 0.0,
@@ -154,7 +268,7 @@ class DevicePER:
         replaces the live item count in the IS weights: sharded PER passes N_global / world (engine.shard_n_is)."""
         n = (n_is if n_is is not None else self.n_items) if begin else None
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s, self.frame_off,
-                         self.frame_bytes, begin_n_items=n, is_n_scale=is_n_scale)
+                         self.win, begin_n_items=n, is_n_scale=is_n_scale)
 
     def _next_buffers(self):
         if getattr(self, "_nxt", None) is None:
@@ -167,7 +281,7 @@ class DevicePER:
         hands it to the conv1 backward launch (ops.hip.conv_bwd(1, ..., sample=...)), which still reads the current
         frame offsets, and ``handover_extra`` to the optimizer launch."""
         idx, prio, gen_s, foff = self._next_buffers()
-        return H.sample_extra(self.tree, self.lay, st, self.seed, idx, prio, self.gen, gen_s, foff, self.frame_bytes,
+        return H.sample_extra(self.tree, self.lay, st, self.seed, idx, prio, self.gen, gen_s, foff, self.win,
                               n_is if n_is is not None else self.n_items, is_n_scale)
 
     def handover_extra(self):
@@ -193,4 +307,4 @@ class DevicePER:
         H.sumtree_update(self.tree, self.lay, idx.contiguous(), val.contiguous())
 
     def remove_to_fit(self) -> int:
-        return 0     # the ring evicts on ingest
+        return 0     # the rings evict on ingest

@@ -1,11 +1,16 @@
 """HBM-resident prioritized *sequence* replay for R2D2 (reference: r2d2/actor.py:56-63 stores
 ``Sequence(transitions, recurrent_state)`` pickles in the same PrioritizedMemory as Ape-X).
 
-Per slot: ``T = burn_in + seq_len`` uint8 frames (zero-padded past ``length``), per-step action / n-step reward /
-done, the true length, and the stored recurrent state ``(h0, c0)`` that preceded frame 0 (r2d2/actor.py:39,57).
-Sampling yields sequence indices plus the *time-major* byte offsets of all ``T·B`` frames, so the time-batched
-torso reads its 7 680 frames straight from this store (no gather, no H2D). Capacity is whatever fits the GPU's
-288 GB (``sequences_that_fit``): 3.4 MB per sequence at full frame stacks.
+Per slot: the ``T = burn_in + seq_len`` observations of the sequence as ``T + 3`` single uint8 PLANES - every frame once
+(VERDICT r1 #5): step t is the 4 consecutive planes from plane t, so the 4-stack that the environments deliver (and that
+overlaps its neighbours in 3 of 4 frames) is never stored: 868 KB per sequence instead of 3.4 MB, 100 K paper-shape
+sequences in 87 GB. Planes 0..2 are the three frames BEFORE the first observation (3 copies of the first frame after a
+reset: wrapped_env.py:32-33), plane 3 + t is the newest frame of observation t; an actor's block still carries full
+stacks (sequences never span episodes: r2d2/actor.py cuts them at ``done``), the split happens on the device at ingest.
+Plus per-step action / n-step reward / done, the true length, and the stored recurrent state ``(h0, c0)`` that preceded
+frame 0 (r2d2/actor.py:39,57). Sampling yields sequence indices plus the *time-major* byte offsets of the plane windows
+of all ``T·B`` observations, so the time-batched torso reads its 7 680 frames straight from this store (no gather, no
+H2D). Capacity is whatever fits the GPU's 288 GB (``sequences_that_fit``).
 """
 from __future__ import annotations
 
@@ -17,25 +22,35 @@ import torch
 from ..config import R2D2Config
 from ..ops import hip as H
 
-FRAME_BYTES = 84 * 84 * 4
+PLANE_BYTES = 84 * 84
+STACK = 4
+FRAME_BYTES = PLANE_BYTES * STACK
 
 
 def sequences_that_fit(free_bytes: int, cfg: R2D2Config, frac: float = 0.6) -> int:
-    per = cfg.total_len * (FRAME_BYTES + 12) + 2 * cfg.hidden * 4 + 64
+    per = (cfg.total_len + STACK - 1) * PLANE_BYTES + cfg.total_len * 12 + 2 * cfg.hidden * 4 + 64
     return int(free_bytes * frac // per)
 
 
+class _SeqBlock:
+    __slots__ = ("slot", "K")
+
+    def __init__(self, slot: int, K: int):
+        self.slot, self.K = slot, K
+
+
 class DeviceSequenceReplay:
-    def __init__(self, capacity: int, device, cfg: R2D2Config, seed: int = 0, frame_bytes: int = FRAME_BYTES):
+    def __init__(self, capacity: int, device, cfg: R2D2Config, seed: int = 0):
         self.capacity, self.cfg = int(capacity), cfg
         self.device = dev = torch.device(device)
         self.T, self.Hd, self.B = cfg.total_len, cfg.hidden, cfg.batch_size
-        self.frame_bytes, self.seed = frame_bytes, seed
+        self.seed = seed
         S, T = self.capacity, self.T
+        self.P = T + STACK - 1                              # planes per sequence slot
         self.lay = H.TreeLayout(S)
         self.tree = torch.zeros(self.lay.total, device=dev)
         self.gen = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.frames = torch.zeros(S * T, frame_bytes, dtype=torch.uint8, device=dev)
+        self.frames = torch.zeros(S * self.P, PLANE_BYTES, dtype=torch.uint8, device=dev)
         self.act = torch.zeros(S, T, dtype=torch.int32, device=dev)
         self.rew = torch.zeros(S, T, device=dev)
         self.done = torch.zeros(S, T, device=dev)
@@ -79,9 +94,19 @@ class DeviceSequenceReplay:
     def retire(self, start: int, K: int) -> None:
         H.sumtree_ingest(self.tree, self.lay, start, None, self.gen, self._scratch, n=K)
 
+    def _write_planes(self, start: int, frames: torch.Tensor) -> None:
+        """frames u8 [K, T, 84, 84, 4] (HWC stacks, any device) -> T + 3 planes per slot: the three older frames of the
+        first stack, then the newest frame of every stack."""
+        K, T, P = int(frames.shape[0]), self.T, self.P
+        fr = frames.reshape(K, T, 84, 84, STACK).to(self.device, non_blocking=True)
+        pl = torch.empty(K, P, 84, 84, dtype=torch.uint8, device=self.device)
+        pl[:, :STACK - 1] = fr[:, 0, :, :, :STACK - 1].permute(0, 3, 1, 2)
+        pl[:, STACK - 1:] = fr[:, :, :, :, STACK - 1]
+        self._ring_write(self.frames, pl.view(K * P, PLANE_BYTES), start, per=P)
+
     def write_slots(self, start: int, frames, action, reward, done, length, h0, c0) -> None:
         K = int(length.shape[0])
-        self._ring_write(self.frames, frames.reshape(K * self.T, -1), start, per=self.T)
+        self._write_planes(start, frames)
         self._ring_write(self.act, action, start)
         self._ring_write(self.rew, reward, start)
         self._ring_write(self.done, done, start)
@@ -93,6 +118,27 @@ class DeviceSequenceReplay:
         self.count = min(self.capacity, self.count + K)
         H.sumtree_ingest(self.tree, self.lay, start, prio, self.gen, self._scratch, n=K, n_items=self.n_items,
                          n_items_val=self.count)
+
+    # block interface of engine/ingest.py (the same three stages as replay/device_per.py)
+    @staticmethod
+    def block_need(kind: int, K: int, M: int = 0):
+        return K, 0
+
+    def reserve_block(self, K: int, M: int = 0) -> _SeqBlock:
+        s = self.reserve(K)
+        self.retire(s, K)
+        return _SeqBlock(s, K)
+
+    def write_views(self, blk: _SeqBlock, kind: int, v) -> None:
+        self.write_slots(blk.slot, v["frames"], v["action"], v["reward"], v["done"], v["length"], v["h0"], v["c0"])
+
+    def commit_block(self, blk: _SeqBlock, prio: torch.Tensor) -> None:
+        self.commit(blk.slot, prio, blk.K)
+
+    def gather_stacks(self, idx: torch.Tensor) -> torch.Tensor:
+        """The observations of the slots ``idx`` as HWC stacks [n, T, 84, 84, 4] (tests / tools)."""
+        pl = self.frames.view(self.capacity, self.P, 84, 84)[idx.long()]
+        return torch.stack([pl[:, k:k + self.T] for k in range(STACK)], -1)
 
     def ingest(self, frames, action, reward, done, length, h0, c0, prio) -> int:
         """K sequences: frames (K,T,…) uint8, action/reward/done (K,T), length (K,), h0/c0 (K,H), prio (K,)."""
@@ -115,7 +161,11 @@ class DeviceSequenceReplay:
         done_n = 0
         while done_n < n:
             k = min(chunk, n - done_n)
-            self.ingest(torch.randint(0, 256, (k, T, self.frame_bytes), dtype=torch.uint8, device=dev, generator=g),
+            s0 = self.reserve(k)                                # random PLANES: nothing to split (benchmarks)
+            self.retire(s0, k)
+            self._ring_write(self.frames, torch.randint(0, 256, (k * self.P, PLANE_BYTES), dtype=torch.uint8, device=dev,
+                                                        generator=g), s0, per=self.P)
+            self._fill_rest(s0, k,
                         torch.randint(0, n_action, (k, T), device=dev, generator=g),
                         torch.randn(k, T, device=dev, generator=g).clamp_(-1, 1),
                         torch.zeros(k, T, device=dev), torch.full((k,), T, dtype=torch.int32, device=dev),
@@ -123,12 +173,18 @@ class DeviceSequenceReplay:
                         torch.rand(k, device=dev, generator=g) + 0.1)
             done_n += k
 
+    def _fill_rest(self, s0, k, action, reward, done, length, h0, c0, prio) -> None:
+        for dst, src in ((self.act, action), (self.rew, reward), (self.done, done), (self.length, length), (self.h0, h0),
+                         (self.c0, c0)):
+            self._ring_write(dst, src.to(dst.dtype), s0)
+        self.commit(s0, prio.contiguous(), k)
+
     # ---- graph-capturable ------------------------------------------------------------------------------
     def sample(self, st: torch.Tensor, begin: bool = False, n_is: Optional[torch.Tensor] = None) -> None:
         """``n_is``: item count used by the IS weights instead of this shard's own (sharded PER: N_global / world)."""
         H.sumtree_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s,
                          begin_n_items=(n_is if n_is is not None else self.n_items) if begin else None)
-        H.seq_offsets(self.idx, self.T, self.frame_bytes, self.frame_off)
+        H.seq_offsets(self.idx, self.T, self.P * PLANE_BYTES, PLANE_BYTES, self.frame_off)
 
     def update(self, new_prio: torch.Tensor, end_state=None, fault=None) -> None:
         H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state, fault=fault)

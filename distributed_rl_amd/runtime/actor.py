@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from ..algo.nstep import SequenceItem
-from ..algo.vec_assembly import VecNStepAssembler, VecSequenceAssembler
+from ..algo.vec_assembly import PlaneLog, VecNStepAssembler, VecSequenceAssembler, plane_block
 from ..config import ApexConfig, R2D2Config
 from ..models.packing import ParamPack
 from ..transport import ExperienceChannel, ParamChannel, codec
@@ -44,13 +44,16 @@ class _LocalApexBuffer:
         self.action = np.zeros(capacity, dtype=np.int32)
         self.reward = np.zeros(capacity, dtype=np.float32)
         self.done = np.zeros(capacity, dtype=np.float32)
+        self.env = np.zeros(capacity, dtype=np.int64)          # source env + positions of s / s' in its plane stream
+        self.qs = np.zeros(capacity, dtype=np.int64)
+        self.qs2 = np.zeros(capacity, dtype=np.int64)
 
     def clear(self):
         self.n = 0
 
     def _drop(self, k: int) -> None:
         rest = self.n - k
-        for a in (self.state, self.next_state, self.action, self.reward, self.done):
+        for a in (self.state, self.next_state, self.action, self.reward, self.done, self.env, self.qs, self.qs2):
             a[:rest] = a[k:self.n]
         self.n = rest
 
@@ -68,6 +71,9 @@ class _LocalApexBuffer:
         n = self.n
         self.state[n:n + k], self.next_state[n:n + k] = b.state, b.next_state
         self.action[n:n + k], self.reward[n:n + k], self.done[n:n + k] = b.action, b.reward, b.done
+        self.env[n:n + k] = b.env
+        if b.qs is not None:
+            self.qs[n:n + k], self.qs2[n:n + k] = b.qs, b.qs2
         self.n = n + k
 
     def __len__(self):
@@ -75,9 +81,68 @@ class _LocalApexBuffer:
 
     def take(self, n: int):
         blk = dict(state=self.state[:n].copy(), next_state=self.next_state[:n].copy(), action=self.action[:n].copy(),
-                   reward=self.reward[:n].copy(), done=self.done[:n].copy())
+                   reward=self.reward[:n].copy(), done=self.done[:n].copy(), env=self.env[:n].copy(), qs=self.qs[:n].copy(),
+                   qs2=self.qs2[:n].copy())
         self._drop(n)
         return blk
+
+
+class _LocalPlaneBuffer:
+    """Actor-side staging when every frame is kept once (PlaneLog): per env, the finished n-step transitions as two
+    positions in the env's plane stream + (action, return, done) - no frames at all. A block is cut from ONE env's
+    transitions (each env then publishes like one actor of the reference: ``actor_batch`` consecutive steps,
+    ape_x/actor.py:86-99), so it spans one run of the stream: ``actor_batch + n + 3`` planes for ``actor_batch``
+    transitions. A block that mixed all envs would carry n + 3 extra planes per env."""
+
+    def __init__(self, num_envs: int, capacity: int):
+        self.E, self.cap = num_envs, capacity
+        self.n = np.zeros(num_envs, dtype=np.int64)
+        self.qs = np.zeros((num_envs, capacity), dtype=np.int64)
+        self.qs2 = np.zeros((num_envs, capacity), dtype=np.int64)
+        self.action = np.zeros((num_envs, capacity), dtype=np.int32)
+        self.reward = np.zeros((num_envs, capacity), dtype=np.float32)
+        self.done = np.zeros((num_envs, capacity), dtype=np.float32)
+
+    def _arrays(self):
+        return self.qs, self.qs2, self.action, self.reward, self.done
+
+    def _drop(self, e: int, k: int) -> None:
+        rest = int(self.n[e]) - k
+        for a in self._arrays():
+            a[e, :rest] = a[e, k:k + rest]
+        self.n[e] = rest
+
+    def extend(self, b) -> None:
+        env = np.asarray(b.env)
+        full = np.unique(env[self.n[env] >= self.cap])
+        for e in full:                                       # bounded deque semantics per env (ReplayMemory(1000), actor.py:49)
+            self._drop(int(e), self.cap // 2)
+        src = (b.qs, b.qs2, b.action, b.reward, b.done)
+        if len(np.unique(env)) == len(env):                  # the usual step: one finished window per env
+            at = self.n[env]
+            for a, v in zip(self._arrays(), src):
+                a[env, at] = v
+            self.n[env] += 1
+            return
+        for i, e in enumerate(env):                          # episode tails: several windows of one env in one step
+            if self.n[e] >= self.cap:
+                self._drop(int(e), self.cap // 2)
+            for a, v in zip(self._arrays(), src):
+                a[e, self.n[e]] = v[i]
+            self.n[e] += 1
+
+    def __len__(self) -> int:
+        return int(self.n.sum())
+
+    def ready(self, k: int):
+        r = np.nonzero(self.n >= k)[0]
+        return int(r[0]) if len(r) else None
+
+    def take(self, e: int, k: int):
+        out = dict(qs=self.qs[e, :k].copy(), qs2=self.qs2[e, :k].copy(), action=self.action[e, :k].copy(),
+                   reward=self.reward[e, :k].copy(), done=self.done[e, :k].copy())
+        self._drop(e, k)
+        return out
 
 
 class Actor:
@@ -113,6 +178,12 @@ class Actor:
             self.asm = VecNStepAssembler(self.E, cfg.nstep, cfg.gamma, cfg.reference_nstep_order,
                                          flush_tail=not cfg.reference_nstep_order)
             self.local = _LocalApexBuffer(cfg.actor_local_capacity)
+            # every frame once on the wire and in the replay: blocks carry the planes their transitions span + two window
+            # positions per transition (codec kind 3). DRL_PLANE_BLOCKS=0: full stacks per transition (kind 1).
+            self.plane_log = None
+            if os.environ.get("DRL_PLANE_BLOCKS", "1") != "0":
+                self.plane_log = PlaneLog(self.E, cap=4 * (cfg.actor_batch + cfg.nstep + 8) + 64)
+                self.local = _LocalPlaneBuffer(self.E, max(2 * cfg.actor_batch, min(cfg.actor_local_capacity, 256)))
         self.env_steps = 0
         self.published_blocks = 0
         self.dropped_blocks = 0
@@ -160,18 +231,45 @@ class Actor:
 
     # ---- publishing -------------------------------------------------------------------------------
     @torch.no_grad()
+    def _publish_apex_planes(self, e: int) -> None:
+        """One env's next ``actor_batch`` transitions as a plane-pool block: the planes they span once + two window
+        positions each; initial priorities from the same pool (no stack is ever materialised on the engine path)."""
+        cfg, t = self.cfg, self.local.take(e, self.cfg.actor_batch)
+        K = len(t["action"])
+        try:
+            planes, win_s, win_s2 = plane_block(self.plane_log, np.full(K, e), t["qs"], t["qs2"])
+        except IndexError:                                   # outlived the plane log (cannot happen with its default size)
+            self.dropped_blocks += 1
+            return
+        if self.engine is not None:
+            prio = self.engine.priorities_planes(planes, win_s, win_s2, t["action"], t["reward"], t["done"], cfg.gamma_n,
+                                                 cfg.per_alpha, cfg.prio_eps)
+        else:
+            dev = self.device
+            ar = np.arange(4)
+            st = lambda w: torch.from_numpy(np.ascontiguousarray(np.transpose(planes[w[:, None] + ar], (0, 2, 3, 1)))).to(dev)  # noqa: E731
+            td = self.net.td_batch(self.net, st(win_s), torch.from_numpy(t["action"]).long().to(dev),
+                                   torch.from_numpy(t["reward"]).to(dev), st(win_s2), torch.from_numpy(t["done"]).to(dev), None,
+                                   cfg.per_alpha, cfg.gamma_n)
+            prio = td.prio.float().cpu().numpy()
+        self._send(dict(planes=planes, win_s=win_s, win_s2=win_s2, action=t["action"], reward=t["reward"], done=t["done"],
+                        prio=prio), codec.KIND_APEX_PLANES)
+
+    @torch.no_grad()
     def _publish_apex(self) -> None:
         blk = self.local.take(self.cfg.actor_batch)
         dev = self.device
         if self.engine is not None:
-            blk["prio"] = self.engine.priorities(blk["state"], blk["next_state"], blk["action"], blk["reward"], blk["done"],
-                                                 self.cfg.gamma_n, self.cfg.per_alpha, self.cfg.prio_eps)
-            self._send(blk, codec.KIND_APEX)
-            return
-        td = self.net.td_batch(self.net, torch.from_numpy(blk["state"]).to(dev), torch.from_numpy(blk["action"]).to(dev),
-                               torch.from_numpy(blk["reward"]).to(dev), torch.from_numpy(blk["next_state"]).to(dev),
-                               torch.from_numpy(blk["done"]).to(dev), None, self.cfg.per_alpha, self.cfg.gamma_n)
-        blk["prio"] = td.prio.float().cpu().numpy()
+            prio = self.engine.priorities(blk["state"], blk["next_state"], blk["action"], blk["reward"], blk["done"],
+                                          self.cfg.gamma_n, self.cfg.per_alpha, self.cfg.prio_eps)
+        else:
+            td = self.net.td_batch(self.net, torch.from_numpy(blk["state"]).to(dev), torch.from_numpy(blk["action"]).to(dev),
+                                   torch.from_numpy(blk["reward"]).to(dev), torch.from_numpy(blk["next_state"]).to(dev),
+                                   torch.from_numpy(blk["done"]).to(dev), None, self.cfg.per_alpha, self.cfg.gamma_n)
+            prio = td.prio.float().cpu().numpy()
+        for k in ("env", "qs", "qs2"):
+            blk.pop(k)
+        blk["prio"] = prio
         self._send(blk, codec.KIND_APEX)
 
     @torch.no_grad()
@@ -253,6 +351,8 @@ class Actor:
         self.env.reset()
         scores = np.zeros(self.E)
         t = 0
+        log = None if self.is_r2d2 else self.plane_log
+        q_state = q_next = None
         t_rep, steps_rep = time.time(), self.env_steps
         while max_steps is None or t < max_steps:
             if stop_event is not None and stop_event.is_set():
@@ -275,7 +375,10 @@ class Actor:
                         else:
                             self.net.reset(torch.from_numpy(done))
                 else:
-                    out = self.asm.step(obs, action, r, next_obs, done)
+                    if log is not None:
+                        q_state = log.observe(obs)                   # position of obs in every env's plane stream ...
+                        q_next = log.observe(next_obs)               # ... and of what the step led to (terminal frames too)
+                    out = self.asm.step(obs, action, r, next_obs, done, q_state, q_next)
                     if out is not None:
                         self.local.extend(out)
             if done.any():
@@ -288,8 +391,15 @@ class Actor:
                 rgb = getattr(self.env, "render_rgb", None)          # emulator screen when there is one, else the newest plane
                 self.metrics.image("Frame %s" % self.name, rgb(0) if rgb is not None else obs[0][..., -1])
             with ph("actor/publish"):
-                while len(self.local) >= cfg.actor_batch:
-                    self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
+                if log is not None:
+                    while True:
+                        e = self.local.ready(cfg.actor_batch)
+                        if e is None:
+                            break
+                        self._publish_apex_planes(e)
+                else:
+                    while len(self.local) >= cfg.actor_batch:
+                        self._publish_r2d2() if self.is_r2d2 else self._publish_apex()
             t += 1
             self.env_steps += self.E
             if t % cfg.actor_param_period == 0:

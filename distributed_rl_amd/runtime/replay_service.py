@@ -23,6 +23,11 @@ from ..transport import ExperienceChannel, codec
 
 def block_to_items(block) -> List:
     """Split a decoded block into per-item tuples for the host PER (copies out of the ring slot)."""
+    if block["kind"] == codec.KIND_APEX_PLANES:                  # plane pool -> the stacks the host PER stores
+        K, pl = block["action"].shape[0], block["planes"]
+        st = lambda w: np.ascontiguousarray(np.transpose(pl[w:w + 4], (1, 2, 0)))   # noqa: E731
+        return [(st(int(block["win_s"][i])), int(block["action"][i]), float(block["reward"][i]),
+                 st(int(block["win_s2"][i])), float(block["done"][i])) for i in range(K)]
     if block["kind"] == codec.KIND_APEX:
         K = block["action"].shape[0]
         return [(block["state"][i].copy(), int(block["action"][i]), float(block["reward"][i]),

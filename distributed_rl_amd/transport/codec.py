@@ -7,6 +7,9 @@ and can be written in place into a shared-memory slot and uploaded to HBM with o
 kind 1 — Ape-X transitions:   state u8[K,*obs], next_state u8[K,*obs], action i32[K], reward f32[K], done f32[K], prio f32[K]
 kind 2 — R2D2 sequences:      frames u8[K,T,*obs], action i32[K,T], reward f32[K,T], done f32[K,T], length i32[K],
                               h0 f32[K,H], c0 f32[K,H], prio f32[K]
+kind 3 — Ape-X transitions over a plane pool (every frame once): planes u8[M,obs0,obs1], win_s i32[K], win_s2 i32[K]
+                              (index of the first of the obs2 consecutive planes that make up s / s'), action, reward, done,
+                              prio as in kind 1. M travels in the header's T field.
 """
 from __future__ import annotations
 
@@ -18,7 +21,7 @@ import numpy as np
 MAGIC = 0x31424C5844  # "DXLB1"
 HEADER = struct.Struct("<QIIIIIIIIQQ")   # magic, kind, K, T, H, obs0, obs1, obs2, actor_id, env_steps, reserved
 HEADER_BYTES = 64
-KIND_APEX, KIND_R2D2 = 1, 2
+KIND_APEX, KIND_R2D2, KIND_APEX_PLANES = 1, 2, 3
 
 
 def _al(n: int) -> int:
@@ -28,6 +31,10 @@ def _al(n: int) -> int:
 def apex_block_bytes(K: int, obs_shape: Tuple[int, int, int]) -> int:
     ob = int(np.prod(obs_shape))
     return HEADER_BYTES + 2 * _al(K * ob) + 4 * _al(4 * K)
+
+
+def apex_planes_block_bytes(K: int, M: int, obs_shape: Tuple[int, int, int]) -> int:
+    return HEADER_BYTES + _al(M * obs_shape[0] * obs_shape[1]) + 6 * _al(4 * K)
 
 
 def r2d2_block_bytes(K: int, T: int, H: int, obs_shape: Tuple[int, int, int]) -> int:
@@ -43,6 +50,9 @@ def _fields(kind: int, K: int, T: int, H: int, obs: Tuple[int, int, int]):
         return [("frames", np.uint8, (K, T) + obs), ("action", np.int32, (K, T)), ("reward", np.float32, (K, T)),
                 ("done", np.float32, (K, T)), ("length", np.int32, (K,)), ("h0", np.float32, (K, H)),
                 ("c0", np.float32, (K, H)), ("prio", np.float32, (K,))]
+    if kind == KIND_APEX_PLANES:
+        return [("planes", np.uint8, (T, obs[0], obs[1])), ("win_s", np.int32, (K,)), ("win_s2", np.int32, (K,)),
+                ("action", np.int32, (K,)), ("reward", np.float32, (K,)), ("done", np.float32, (K,)), ("prio", np.float32, (K,))]
     raise ValueError("unknown block kind %d" % kind)
 
 
@@ -52,6 +62,9 @@ def encode_into(buf, block: Dict[str, np.ndarray], kind: int, actor_id: int = 0,
     if kind == KIND_APEX:
         K = int(block["action"].shape[0]); T = 0; H = 0
         obs = tuple(int(x) for x in block["state"].shape[1:])
+    elif kind == KIND_APEX_PLANES:
+        K = int(block["action"].shape[0]); T = int(block["planes"].shape[0]); H = 0
+        obs = (int(block["planes"].shape[1]), int(block["planes"].shape[2]), int(block.get("stack", 4)))
     else:
         K, T = (int(x) for x in block["action"].shape)
         H = int(block["h0"].shape[1])
@@ -69,6 +82,8 @@ def encode_into(buf, block: Dict[str, np.ndarray], kind: int, actor_id: int = 0,
 def encode(block: Dict[str, np.ndarray], kind: int, actor_id: int = 0, env_steps: int = 0) -> bytearray:
     if kind == KIND_APEX:
         n = apex_block_bytes(block["action"].shape[0], tuple(block["state"].shape[1:]))
+    elif kind == KIND_APEX_PLANES:
+        n = apex_planes_block_bytes(block["action"].shape[0], block["planes"].shape[0], tuple(block["planes"].shape[1:]) + (4,))
     else:
         n = r2d2_block_bytes(block["action"].shape[0], block["action"].shape[1], block["h0"].shape[1],
                              tuple(block["frames"].shape[2:]))
@@ -84,7 +99,7 @@ def layout(buf):
     magic, kind, K, T, H, o0, o1, o2, actor_id, env_steps, _ = HEADER.unpack_from(mv, 0)
     if magic != MAGIC:
         raise ValueError("bad experience block magic")
-    meta = {"kind": kind, "K": K, "actor_id": actor_id, "env_steps": env_steps}
+    meta = {"kind": kind, "K": K, "M": T if kind == KIND_APEX_PLANES else 0, "actor_id": actor_id, "env_steps": env_steps}
     off, out = HEADER_BYTES, []
     for name, dt, shape in _fields(kind, K, T, H, (o0, o1, o2)):
         nb = int(np.prod(shape)) * np.dtype(dt).itemsize

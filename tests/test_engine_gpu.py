@@ -34,8 +34,7 @@ def _setup(B=64, cap=1000, A=6, seed=0, rms_eps=None):
 def _reference(model, target, cfg, rep, eng):
     B = cfg.batch_size
     idx = rep.idx.long()
-    s = rep.frames[:rep.capacity][idx].view(B, 84, 84, 4).cpu()
-    s2 = rep.frames[rep.capacity:][idx].view(B, 84, 84, 4).cpu()
+    s, s2 = (t.cpu() for t in rep.gather_stacks(idx))              # the plane windows as the stacks the networks see
     a, r, d = rep.act[idx].cpu().long(), rep.rew[idx].cpu(), rep.done[idx].cpu()
     st = eng.stats()
     w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"])
@@ -65,7 +64,9 @@ def test_apex_engine_step_matches_oracle():
         g, ref = grads[name], p.grad
         errs[name] = (float((g - ref).norm() / (ref.norm() + 1e-12)), float(ref.norm()), float(g.norm()))
     print(errs)
-    assert all(e[0] < 6e-2 for e in errs.values()), errs
+    # bf16 STORAGE of activations / activation gradients against an fp32 oracle: 5-7 % on random frames at this batch size
+    # (tests/test_production_gpu.py separates it from kernel error with a storage-emulating oracle: <= 1.4 % there)
+    assert all(e[0] < 8e-2 for e in errs.values()), errs
     # optimizer: same gradients through torch RMSprop + clip
     opt = torch.optim.RMSprop(model.parameters(), lr=cfg.lr, alpha=cfg.rms_alpha, eps=cfg.rms_eps)
     with torch.no_grad():
@@ -197,21 +198,27 @@ def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
 
 
 def test_device_per_block_ingest_roundtrip():
+    """Three full-stack blocks of 30 into a 64-slot replay: the third does not fit behind the second, starts over at slot 0 /
+    plane 0 and evicts the first (whole blocks, FIFO); the second stays live and intact."""
     import numpy as np
     from distributed_rl_amd.replay.device_per import DevicePER
-    rep = DevicePER(64, "cuda", batch_size=8)
+    rep = DevicePER(64, "cuda", batch_size=8, plane_capacity=528)
     rng = np.random.default_rng(0)
+    blks = []
     for k in range(3):
         blk = dict(state=rng.integers(0, 256, (30, 84, 84, 4), dtype=np.uint8), next_state=rng.integers(0, 256, (30, 84, 84, 4), dtype=np.uint8),
                    action=rng.integers(0, 4, 30).astype(np.int32), reward=rng.random(30).astype(np.float32),
                    done=np.zeros(30, np.float32), prio=(rng.random(30) + 0.1).astype(np.float32))
         rep.ingest_block(blk)
-    assert len(rep) == 64 and rep.cursor == 90 % 64
-    # last block occupies slots 60..63,0..25
-    assert np.array_equal(rep.frames[60].cpu().numpy(), blk["state"][0].reshape(-1))
-    assert np.array_equal(rep.frames[64 + 25].cpu().numpy(), blk["next_state"][29].reshape(-1))
+        blks.append(blk)
+    assert len(rep) == 60 and rep.cursor == 30 and rep.pcursor == 240 and int(rep.n_items.item()) == 60
+    assert [(b.slot, b.plane) for b in rep._blocks] == [(30, 240), (0, 0)]
+    for blk, slot in ((blks[1], 30), (blks[2], 0)):
+        s_, s2_ = rep.gather_stacks(torch.arange(slot, slot + 30, device="cuda"))
+        assert np.array_equal(s_.cpu().numpy(), blk["state"]) and np.array_equal(s2_.cpu().numpy(), blk["next_state"])
+    assert float(rep.tree[60:64].abs().sum()) == 0.0                  # the skipped tail was never written
     assert rep.total_prios() == pytest.approx(float(rep.tree[:64].sum()), rel=1e-6)
-    assert int(rep.gen[0]) == 2 and int(rep.gen[59]) == 1
+    assert int(rep.gen[0]) == 3 and int(rep.gen[59]) == 1       # slot 0: committed, retired, committed again
 
 
 # ---- R2D2 ------------------------------------------------------------------------------------------------
@@ -253,7 +260,7 @@ def test_r2d2_engine_step_matches_oracle():
     torch.cuda.synchronize()
     B, T = cfg.batch_size, cfg.total_len
     idx = rep.idx.long().cpu()
-    frames = rep.frames.view(rep.capacity, T, 84, 84, 4)[idx.cuda()].permute(1, 0, 2, 3, 4).contiguous().cpu()
+    frames = rep.gather_stacks(idx.cuda()).permute(1, 0, 2, 3, 4).contiguous().cpu()
     a = rep.act.cpu()[idx].t().long()
     r = rep.rew.cpu()[idx].t()
     d = rep.done.cpu()[idx].t()

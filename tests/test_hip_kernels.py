@@ -436,6 +436,18 @@ def _conv_setup(layer, frames, seed):
     return x, xf, w, bias, (cin, cout, ks, s, hw)
 
 
+def _plane_store(stacks):
+    """HWC stacks u8 [n,84,84,4] -> a plane store [4n, 7056] (every stack as 4 consecutive planes) + the byte offset of
+    every stack's window; the replay keeps shared planes once, for the kernels only the offsets matter."""
+    n = stacks.shape[0]
+    return stacks.permute(0, 3, 1, 2).reshape(n * 4, 7056).contiguous(), torch.arange(n) * (4 * 7056)
+
+
+def _w1_planes(w):
+    """conv1 weights [32,kh,kw,c] (dense HWC input) -> [32,c,kh,kw] (plane store input; PyTorch's own order)."""
+    return w.permute(0, 3, 1, 2).contiguous()
+
+
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("frames", [1, 7, 96, 700])
 @pytest.mark.parametrize("direct", [-1, 0, 1, 2, 3, -2, -3, -4])          # < -1: tiled kernel with the LDS-DMA mainloop
@@ -451,17 +463,29 @@ def test_conv_fwd(hip, layer, frames, direct):
 
 
 def test_conv1_frame_offsets(hip):
+    """conv1 over the replay's plane store (frame = 4 consecutive planes from a byte offset, weights [32,c,kh,kw]) ==
+    conv1 over the same frames as dense HWC stacks (weights [32,kh,kw,c]), for the direct and the tiled kernel; windows
+    that OVERLAP (a stack shifted by one plane, as consecutive observations are stored) included."""
     H = hip
-    store = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    stacks = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    store, off = _plane_store(stacks)
     pick = torch.tensor([7, 3, 19, 7, 0])
     _, _, w, bias, _ = _conv_setup(1, 1, 5)
     out = torch.zeros(5, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
     for direct in (False, True):
         out.zero_()
-        H.conv_fwd(1, store.to(DEV), w.to(DEV), bias.to(DEV), out, 5, frame_off=(pick * 28224).to(DEV), direct=direct)
+        H.conv_fwd(1, store.to(DEV), _w1_planes(w).to(DEV), bias.to(DEV), out, 5, frame_off=off[pick].to(DEV), direct=direct)
         ref = torch.zeros_like(out)
-        H.conv_fwd(1, store[pick].contiguous().to(DEV), w.to(DEV), bias.to(DEV), ref, 5, direct=direct)
-        assert torch.equal(out, ref)
+        H.conv_fwd(1, stacks[pick].contiguous().to(DEV), w.to(DEV), bias.to(DEV), ref, 5, direct=direct)
+        # same products, another summation order (k = (c, kh, kw) against (kh, kw, c)): equal up to one bf16 rounding
+        torch.testing.assert_close(out.float(), ref.float(), rtol=8e-3, atol=4e-3)
+    # windows shifted by 1..3 planes: planes (4 i + k .. 4 i + k + 3) = the stack [c_k.., next stack's c_0..]
+    shift = torch.tensor([1, 2, 3, 5, 9])
+    dense = store.view(-1, 84, 84)[(shift[:, None] + torch.arange(4)[None, :])].permute(0, 2, 3, 1).contiguous()
+    H.conv_fwd(1, store.to(DEV), _w1_planes(w).to(DEV), bias.to(DEV), out, 5, frame_off=(shift * 7056).to(DEV))
+    ref = torch.zeros_like(out)
+    H.conv_fwd(1, dense.to(DEV), w.to(DEV), bias.to(DEV), ref, 5)
+    torch.testing.assert_close(out.float(), ref.float(), rtol=8e-3, atol=4e-3)
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
@@ -475,11 +499,9 @@ def test_conv_fwd_dual(hip, layer, f1, f2):
     o1 = torch.zeros(f1, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
     o2 = torch.zeros(f2, oh, oh, cout, dtype=torch.bfloat16, device=DEV)
     if layer == 1:
-        store = torch.cat([x1, x2]).to(DEV)
-        off1 = (torch.arange(f1) * 28224).to(DEV)
-        off2 = ((f1 + torch.arange(f2)) * 28224).to(DEV)
-        H.conv_fwd_dual(1, store, f1, w1.to(DEV), b1.to(DEV), o1, None, f2, w2.to(DEV), b2.to(DEV), o2,
-                        frame_off1=off1, frame_off2=off2)
+        store, off = _plane_store(torch.cat([x1, x2]))
+        H.conv_fwd_dual(1, store.to(DEV), f1, _w1_planes(w1).to(DEV), b1.to(DEV), o1, None, f2, _w1_planes(w2).to(DEV), b2.to(DEV),
+                        o2, frame_off1=off[:f1].to(DEV), frame_off2=off[f1:].to(DEV))
     else:
         H.conv_fwd_dual(layer, x1.to(DEV), f1, w1.to(DEV), b1.to(DEV), o1, x2.to(DEV), f2, w2.to(DEV), b2.to(DEV), o2)
     for o, xf, w, b in ((o1, xf1, w1, b1), (o2, xf2, w2, b2)):
@@ -691,18 +713,23 @@ def test_conv_bwd_fused_tree_stages(hip, cap):
 
 
 def test_conv1_bwd_fused_frame_offsets(hip):
+    """conv1 weight + bias gradient over the plane store ([32,c,kh,kw]) == the dense HWC form ([32,kh,kw,c]) permuted."""
     H = hip
-    store = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    stacks = torch.randint(0, 256, (20, 84, 84, 4), dtype=torch.uint8)
+    store, off = _plane_store(stacks)
     pick = torch.tensor([7, 3, 19, 7, 0])
     g = torch.Generator().manual_seed(14)
     dy = bf(torch.randn(5, 20, 20, 32, generator=g) * 0.1).to(DEV)
-    dw, db = torch.zeros(32, 8, 8, 4, device=DEV), torch.zeros(32, device=DEV)
-    H.conv_bwd(1, store.to(DEV), dy, None, dw, db, None, 5, frame_off=(pick * 28224).to(DEV), splits=4)
-    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
-    H.conv_wgrad(1, store[pick].contiguous().to(DEV), dy, dw2, 5, splits=1)
+    dw, db = torch.zeros(32, 4, 8, 8, device=DEV), torch.zeros(32, device=DEV)
+    H.conv_bwd(1, store.to(DEV), dy, None, dw, db, None, 5, frame_off=off[pick].to(DEV), splits=4)
+    dw2, db2 = torch.zeros(32, 8, 8, 4, device=DEV), torch.zeros_like(db)
+    H.conv_wgrad(1, stacks[pick].contiguous().to(DEV), dy, dw2, 5, splits=1)
     H.colsum(dy, db2, 5 * 400, 32)
-    torch.testing.assert_close(dw, dw2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw, _w1_planes(dw2), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-5)
+    dw3 = torch.zeros_like(dw)
+    H.conv_wgrad(1, store.to(DEV), dy, dw3, 5, frame_off=off[pick].to(DEV), splits=2)
+    torch.testing.assert_close(dw3, _w1_planes(dw2), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("M,A,with_head,variant", [(512, 4, True, None), (64, 18, True, 0), (100, 6, False, 2), (70, 4, True, 5)])
@@ -862,10 +889,10 @@ def test_lstm_bptt_persistent_matches_step_launches(hip, M):
 def test_conv1_fwd_pair_matches_single_network_launches(hip, frames):
     """Two weight sets per tile over the same frames: bit-identical to two single-network launches."""
     H = hip
-    store = torch.randint(0, 256, (frames + 7, 84, 84, 4), dtype=torch.uint8).to(DEV)
-    off = (torch.randperm(frames + 7)[:frames] * 28224).to(DEV)
+    store = torch.randint(0, 256, (4 * (frames + 7), 7056), dtype=torch.uint8).to(DEV)         # a plane store
+    off = (torch.randperm(4 * (frames + 7) - 3)[:frames] * 7056).to(DEV)                       # any 4 consecutive planes
     outs = []
-    nets = [_conv_setup(1, 1, 40 + i)[2:4] for i in range(2)]
+    nets = [(_w1_planes(w), b) for w, b in (_conv_setup(1, 1, 40 + i)[2:4] for i in range(2))]
     for w, b in nets:
         o = torch.zeros(frames, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
         H.conv_fwd(1, store, w.to(DEV), b.to(DEV), o, frames, frame_off=off)
@@ -879,9 +906,9 @@ def test_conv1_fwd_apex_layout_matches_single_network_launches(hip):
     """Network 1 on [s ; s'], network 2 on s' with the s' tiles shared: bit-identical to single-network launches."""
     H = hip
     B = 37
-    store = torch.randint(0, 256, (2 * B + 3, 84, 84, 4), dtype=torch.uint8).to(DEV)
-    off = (torch.randperm(2 * B + 3)[:2 * B] * 28224).to(DEV)
-    (w1, b1), (w2, b2) = [tuple(t.to(DEV) for t in _conv_setup(1, 1, 60 + i)[2:4]) for i in range(2)]
+    store = torch.randint(0, 256, (4 * (2 * B + 3), 7056), dtype=torch.uint8).to(DEV)
+    off = (torch.randperm(4 * (2 * B + 3) - 3)[:2 * B] * 7056).to(DEV)
+    (w1, b1), (w2, b2) = [(_w1_planes(w).to(DEV), b.to(DEV)) for w, b in (_conv_setup(1, 1, 60 + i)[2:4] for i in range(2))]
     ref1 = torch.zeros(2 * B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
     ref2 = torch.zeros(B, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
     H.conv_fwd(1, store, w1, b1, ref1, 2 * B, frame_off=off)

@@ -19,71 +19,97 @@ def _apex_block(rng, K, lo=0.5):
                 done=(rng.random(K) < 0.1).astype(np.float32), prio=(rng.random(K) + lo).astype(np.float32))
 
 
+def _plane_block(rng, runs, run, n=3):
+    """A kind-3 block as the vectorised actor ships it: ``runs`` runs of ``run`` consecutive steps (s' = n steps on)."""
+    per = run + n + 3
+    planes = rng.integers(0, 256, (runs * per, 84, 84), dtype=np.uint8)
+    i = np.arange(runs * run)
+    ws = ((i // run) * per + i % run).astype(np.int32)
+    K = len(i)
+    return dict(planes=planes, win_s=ws, win_s2=(ws + n).astype(np.int32), action=rng.integers(0, 4, K).astype(np.int32),
+                reward=rng.standard_normal(K).astype(np.float32), done=(rng.random(K) < 0.1).astype(np.float32),
+                prio=(rng.random(K) + 0.5).astype(np.float32))
+
+
+def _stack_of(planes, w):
+    return np.ascontiguousarray(np.transpose(planes[w:w + 4], (1, 2, 0)))
+
+
 def test_async_ingest_apex_while_stepping(run_id):
+    """Blocks of both wire kinds (full stacks, plane pools) through shm ring -> pinned staging -> side-stream DMA while the
+    graph-captured engine keeps stepping; enough of them to wrap both rings of the replay. Every transition still live
+    afterwards reads back as the stacks the actor saw."""
     from distributed_rl_amd.engine.apex import ApexEngine
     from distributed_rl_amd.engine.ingest import AsyncIngest
     from distributed_rl_amd.replay.device_per import DevicePER
     dev = torch.device("cuda")
     cap, B = 300, 32
-    rep = DevicePER(cap, dev, batch_size=B, seed=3)
+    rep = DevicePER(cap, dev, batch_size=B, seed=3, plane_capacity=1500)
     rep.fill_synthetic(100)
     eng = ApexEngine(4, ApexConfig(batch_size=B), rep, dev)
     eng.step()                                                       # warm-up + capture
     ring = ShmExperience(shm_names(run_id)[0], create=True, n_slots=8, slot_bytes=4 << 20)
     pipe = AsyncIngest(ring, rep, dev, depth=3)
     rng = np.random.default_rng(0)
-    blocks = [_apex_block(rng, K) for K in (40, 64, 17, 64, 64, 50)]          # 299 items: wraps the 300-slot ring
-    try:
-        sent, start = 0, rep.cursor
-        expect = {}
-        pos = start
-        for b in blocks:
-            for i in range(b["action"].shape[0]):
-                expect[(pos + i) % cap] = (b, i)
-            pos += b["action"].shape[0]
-        t0 = time.time()
-        committed = 0
-        while committed < 299 and time.time() - t0 < 60:
-            if sent < len(blocks) and ring.push(blocks[sent], codec.KIND_APEX, 1, sent):
+    blocks = [(_apex_block(rng, 40), codec.KIND_APEX), (_plane_block(rng, 4, 16), codec.KIND_APEX_PLANES),
+              (_apex_block(rng, 17), codec.KIND_APEX), (_plane_block(rng, 2, 32), codec.KIND_APEX_PLANES),
+              (_plane_block(rng, 8, 8), codec.KIND_APEX_PLANES), (_apex_block(rng, 50), codec.KIND_APEX),
+              (_plane_block(rng, 3, 20), codec.KIND_APEX_PLANES)]
+    total = sum(b["action"].shape[0] for b, _ in blocks)              # 40 + 64 + 17 + 64 + 64 + 50 + 60 = 359 > 300 slots;
+    try:                                                              # planes: 320 + 88 + 136 + 76 + 112 + 400 + 78
+        sent, committed, t0 = 0, 0, time.time()
+        while committed < total and time.time() - t0 < 60:
+            if sent < len(blocks) and ring.push(blocks[sent][0], blocks[sent][1], 1, sent):
                 sent += 1
             committed += pipe.service()
             eng.step()                                               # graph replays interleaved with the DMA
             # between retire and commit a slot has priority 0: whatever the sampler drew has a positive priority
             assert float(rep.prio.min()) > 0.0
-        assert committed == 299 and pipe.pending() == 0
+        assert committed == total and pipe.pending() == 0
         torch.cuda.synchronize()
         eng.stats()
-        assert len(rep) == cap and int(rep.n_items.item()) == cap     # count written by the commit launch
-        fr = rep.frames.view(2, cap, 84, 84, 4)
-        for slot in (start % cap, (start + 39) % cap, (start + 40) % cap, (start + 200) % cap, (start + 298) % cap):
-            b, i = expect[slot]
-            assert np.array_equal(fr[0, slot].cpu().numpy(), b["state"][i])
-            assert np.array_equal(fr[1, slot].cpu().numpy(), b["next_state"][i])
-            assert int(rep.act[slot]) == int(b["action"][i]) and float(rep.rew[slot]) == float(b["reward"][i])
-            assert float(rep.done[slot]) == float(b["done"][i])
+        live = sum(b.K for b in rep._blocks)
+        assert len(rep) == live == int(rep.n_items.item()) and 0 < live <= cap     # count written by the commit launch
+        # every block still owning its ranges reads back exactly; the blocks come back in ingestion order
+        recs = list(rep._blocks)
+        assert [r.K for r in recs[-3:]] == [64, 50, 60]
+        for rec, (b, kind) in zip(recs[-3:], blocks[-3:]):
+            slots = torch.arange(rec.slot, rec.slot + rec.K, device=dev)
+            s_, s2_ = rep.gather_stacks(slots)
+            for i in (0, rec.K // 2, rec.K - 1):
+                if kind == codec.KIND_APEX:
+                    es, es2 = b["state"][i], b["next_state"][i]
+                else:
+                    es, es2 = _stack_of(b["planes"], b["win_s"][i]), _stack_of(b["planes"], b["win_s2"][i])
+                assert np.array_equal(s_[i].cpu().numpy(), es) and np.array_equal(s2_[i].cpu().numpy(), es2)
+                assert int(rep.act[rec.slot + i]) == int(b["action"][i]) and float(rep.rew[rec.slot + i]) == float(b["reward"][i])
+                assert float(rep.done[rec.slot + i]) == float(b["done"][i])
+        # nothing outside the live blocks can be drawn: the leaves of every other slot are zero
+        mask = torch.zeros(cap, dtype=torch.bool, device=dev)
+        for r in recs:
+            mask[r.slot:r.slot + r.K] = True
+        assert float(rep.tree[:cap][~mask].abs().sum()) == 0.0 and float(rep.tree[:cap][mask].min()) > 0.0
         # tree is exact: root == sum of leaves (leaves were partly rewritten by the engine's priority write-backs)
         leaves = rep.tree[:cap].double().sum().item()
         assert rep.total_prios() == pytest.approx(leaves, rel=1e-5)
         st = pipe.stats()
-        assert st["items"] == 299 and st["blocks"] == 6 and st["bytes"] > 299 * 2 * 28224
+        assert st["items"] == total and st["blocks"] == len(blocks)
     finally:
         pipe.close()
         ring.close()
 
 
 def test_async_ingest_retired_slots_are_not_sampled_and_stale_writebacks_dropped(run_id):
-    from distributed_rl_amd.engine.ingest import AsyncIngest
     from distributed_rl_amd.ops import hip as H
     from distributed_rl_amd.replay.device_per import DevicePER
     dev = torch.device("cuda")
     rep = DevicePER(64, dev, batch_size=64, seed=1)
-    rep.fill_synthetic(64)
+    rep.fill_synthetic(64, run=32)
     st = H.new_step_state(dev, 0.4, 1e-6)
     gen0 = rep.gen.clone()
     rep.sample(st, begin=True)
     idx_before = rep.idx.clone()
-    s = rep.reserve(32)                                               # slots 0..31 leave the tree
-    rep.retire(s, 32)
+    rep._retire(0, 32)                                                # what reserve_block does to a range: slots 0..31 leave the tree
     for _ in range(20):
         rep.sample(st, begin=True)
         assert int(rep.idx.min()) >= 32                              # never drawn while retired
@@ -93,7 +119,9 @@ def test_async_ingest_retired_slots_are_not_sampled_and_stale_writebacks_dropped
     rep.gen_s.copy_(gen0[idx_before.long()])
     rep.update(torch.full((64,), 123.0, device=dev))
     assert float(rep.tree[:32].abs().sum()) == 0.0
-    rep.commit(s, torch.full((32,), 2.0, device=dev), 32)
+    from distributed_rl_amd.replay.device_per import _Block
+    rep.count = 32
+    rep.commit_block(_Block(0, 32, 0, 36), torch.full((32,), 2.0, device=dev))
     assert float(rep.tree[:32].sum()) == 64.0 and int(rep.n_items.item()) == 64
 
 
@@ -109,7 +137,9 @@ def test_async_ingest_r2d2_inproc_channel(run_id):
     pipe = AsyncIngest(exp, rep, dev, depth=2, slot_bytes=4 << 20)
     rng = np.random.default_rng(0)
     K, T = 5, cfg.total_len
-    blk = dict(frames=rng.integers(0, 256, (K, T, 84, 84, 4), dtype=np.uint8), action=rng.integers(0, 4, (K, T)).astype(np.int32),
+    planes = rng.integers(0, 256, (K, T + 3, 84, 84), dtype=np.uint8)          # what an environment's frame stack is made of
+    frames = np.stack([planes[:, k:k + T] for k in range(4)], -1)                # [K, T, 84, 84, 4]: observation t = planes t..t+3
+    blk = dict(frames=frames, action=rng.integers(0, 4, (K, T)).astype(np.int32),
                reward=rng.standard_normal((K, T)).astype(np.float32), done=np.zeros((K, T), np.float32),
                length=np.array([T, T, T - 1, T, 3], np.int32), h0=rng.standard_normal((K, 512)).astype(np.float32),
                c0=rng.standard_normal((K, 512)).astype(np.float32), prio=(rng.random(K) + 0.5).astype(np.float32))
@@ -122,9 +152,65 @@ def test_async_ingest_r2d2_inproc_channel(run_id):
             time.sleep(0.001)
         assert n == K and len(rep) == K and int(rep.n_items.item()) == K
         torch.cuda.synchronize()
-        assert np.array_equal(rep.frames.view(16, T, 84, 84, 4)[2].cpu().numpy(), blk["frames"][2])
+        assert np.array_equal(rep.frames.view(16, T + 3, 84, 84)[2].cpu().numpy(), planes[2])      # every frame once
+        assert np.array_equal(rep.gather_stacks(torch.tensor([2, 4], device=dev)).cpu().numpy(), blk["frames"][[2, 4]])
         assert np.array_equal(rep.length[:K].cpu().numpy(), blk["length"])
         np.testing.assert_array_equal(rep.h0[:K].cpu().numpy(), blk["h0"])
         np.testing.assert_allclose(rep.tree[:K].cpu().numpy(), blk["prio"])
     finally:
         pipe.close()
+
+
+def test_plane_store_against_the_host_oracle_through_episode_boundaries(run_id):
+    """The actor's own plane-pool blocks (SyntheticCatch with one life: a reset every ~26 steps, truncated n-step tails onto
+    terminal frames) into a replay small enough to lap both rings several times: every transition that is still live reads
+    back - through the sampled-window path the kernels use - as exactly the stacks the host replay of the PyTorch learner
+    would hold (runtime/replay_service.block_to_items), and nothing else can be drawn."""
+    from distributed_rl_amd.envs.synthetic import CatchVecEnv
+    from distributed_rl_amd.models import DuelingDQN
+    from distributed_rl_amd.replay.device_per import DevicePER
+    from distributed_rl_amd.runtime.actor import Actor
+    from distributed_rl_amd.runtime.replay_service import block_to_items
+    from distributed_rl_amd.transport import connect
+    from distributed_rl_amd.config import make_config
+    dev = torch.device("cuda")
+    cfg = make_config("ape_x", actor_batch=40, nstep=3)
+    exp, par = connect("inproc", run_id, create=True)
+    E = 8
+    actor = Actor(1, CatchVecEnv(E, seed=0, lives=1), DuelingDQN(4), cfg, exp, par, None, 1, torch.device("cpu"), seed=0)
+    actor.run(max_steps=140)
+    blocks = exp.drain(1 << 20)
+    assert len(blocks) >= 20 and all(b["kind"] == codec.KIND_APEX_PLANES for b in blocks)
+    assert sum(b["planes"].shape[0] for b in blocks) < 1.5 * sum(b["action"].shape[0] for b in blocks)    # vs 8 as stacks
+    rep = DevicePER(300, dev, batch_size=16, seed=0, plane_capacity=700)
+    owner = {}
+    for b in blocks:
+        rep.ingest_block(b)
+        rec = rep._blocks[-1]
+        items = block_to_items(b)
+        for s in list(owner):                                          # whatever the replay evicted is gone from the oracle
+            if not any(r.slot <= s < r.slot + r.K for r in rep._blocks if r.state == 1):
+                del owner[s]
+        for i, it in enumerate(items):
+            owner[rec.slot + i] = (it, float(b["prio"][i]))
+    torch.cuda.synchronize()
+    live = sorted(owner)
+    assert len(live) == len(rep) == int(rep.n_items.item()) and 100 < len(live) <= 300
+    s_, s2_ = rep.gather_stacks(torch.tensor(live, device=dev))
+    s_, s2_ = s_.cpu().numpy(), s2_.cpu().numpy()
+    for j, slot in enumerate(live):
+        (s, a, r, s2, d), p = owner[slot]
+        assert np.array_equal(s_[j], s) and np.array_equal(s2_[j], s2)
+        assert int(rep.act[slot]) == a and float(rep.rew[slot]) == pytest.approx(r) and float(rep.done[slot]) == d
+        assert float(rep.tree[slot]) == pytest.approx(p)
+    dead = torch.ones(300, dtype=torch.bool, device=dev)
+    dead[torch.tensor(live, device=dev)] = False
+    assert float(rep.tree[:300][dead].abs().sum()) == 0.0            # evicted / never written slots cannot be drawn
+    # and the sampler hands the kernels exactly these windows
+    from distributed_rl_amd.ops import hip as H
+    st = H.new_step_state(dev, 0.4, 1e-6)
+    rep.sample(st, begin=True)
+    torch.cuda.synchronize()
+    idx = rep.idx.long()
+    assert torch.equal(rep.frame_off[:16], rep.win[idx]) and torch.equal(rep.frame_off[16:], rep.win[300 + idx])
+    assert all(int(i) in owner for i in idx.cpu())

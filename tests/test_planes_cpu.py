@@ -1,0 +1,103 @@
+"""Every frame once: the actor-side plane stream (algo/vec_assembly.PlaneLog), the positions the n-step
+assembler attaches to its transitions and the plane-pool wire block (codec kind 3), against the full stacks the same
+assembler emits - episode starts (reset stack = 4 copies + no-ops), episode tails (truncated n-step windows onto the
+terminal frame), environments that do not stack at all, a log that is too small."""
+import numpy as np
+import pytest
+
+from distributed_rl_amd.algo.vec_assembly import PlaneLog, VecNStepAssembler, plane_block
+from distributed_rl_amd.envs.synthetic import CatchVecEnv, RandomFrameVecEnv
+from distributed_rl_amd.runtime.replay_service import block_to_items
+from distributed_rl_amd.transport import codec
+
+
+def _stack(planes, w):
+    return np.ascontiguousarray(np.transpose(planes[w:w + 4], (1, 2, 0)))
+
+
+def _drive(env, E, n, steps, cap=64, seed=0):
+    asm = VecNStepAssembler(E, n, 0.99)
+    log = PlaneLog(E, cap=cap)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    batches, episodes = [], 0
+    for _ in range(steps):                                        # the actor's loop (runtime/actor.py)
+        obs = env.current_obs()
+        qs = log.observe(obs)
+        act = rng.integers(0, 4, E)
+        nxt, r, d, _ = env.step(act)
+        qn = log.observe(nxt)
+        out = asm.step(obs, act, r, nxt, d, qs, qn)
+        if out is not None:
+            planes, ws, ws2 = plane_block(log, out.env, out.qs, out.qs2)
+            batches.append((out, planes, ws, ws2))
+        episodes += int(d.sum())
+    return batches, episodes, log
+
+
+def test_plane_positions_reproduce_every_stack_across_episode_boundaries():
+    E, n = 6, 3
+    batches, episodes, log = _drive(CatchVecEnv(E, seed=0, lives=1), E, n, 300)
+    assert episodes > 30                                          # many resets and truncated tails in the run
+    tails = total = 0
+    for out, planes, ws, ws2 in batches:
+        for i in range(len(out.env)):
+            assert np.array_equal(_stack(planes, ws[i]), out.state[i])
+            assert np.array_equal(_stack(planes, ws2[i]), out.next_state[i])
+        # inside an episode s' is exactly n planes on; only the truncated windows at an episode's end are closer
+        gap = out.qs2 - out.qs
+        assert gap.max() <= n and gap.min() >= 1 and np.all(gap[out.done == 0] == n)
+        tails += int((gap < n).sum())
+        total += len(gap)
+    assert tails > 30 and total > 1500
+    assert log.head.sum() / (300 * E) < 1.25                      # ~1 plane per env step + 4 per reset (full stacks: 8)
+
+
+def test_an_env_that_does_not_stack_is_stored_exactly_just_not_compressed():
+    E, n = 3, 2
+    batches, _, log = _drive(RandomFrameVecEnv(E, 4, episode_len=17, seed=1), E, n, 60, cap=256)
+    for out, planes, ws, ws2 in batches:
+        for i in range(len(out.env)):
+            assert np.array_equal(_stack(planes, ws[i]), out.state[i])
+            assert np.array_equal(_stack(planes, ws2[i]), out.next_state[i])
+    assert log.head.sum() >= 4 * 2 * 60 * E                       # every observation (s and s' differ here) entered whole
+
+
+def test_plane_log_refuses_positions_it_no_longer_holds():
+    log = PlaneLog(1, cap=8)
+    obs = np.zeros((1, 84, 84, 4), np.uint8)
+    log.observe(obs)
+    for k in range(1, 12):
+        nxt = np.ascontiguousarray(np.concatenate([obs[..., 1:], np.full((1, 84, 84, 1), k, np.uint8)], -1))
+        log.observe(nxt)
+        assert int(log.observe(nxt)[0]) == k                      # seeing it again changes nothing
+        obs = nxt
+    assert int(log.q[0]) == 11 and int(log.head[0]) == 15
+    assert np.array_equal(log.planes(0, 11, 14)[:, 0, 0], [8, 9, 10, 11])
+    with pytest.raises(IndexError):
+        log.planes(0, 3, 6)                                       # overwritten
+    with pytest.raises(IndexError):
+        log.planes(0, 12, 15)                                     # not there yet
+
+
+def test_plane_block_wire_format_roundtrip_and_host_replay_items():
+    E, n = 4, 3
+    batches, _, log = _drive(CatchVecEnv(E, seed=3, lives=2), E, n, 16)
+    from distributed_rl_amd.algo.nstep import NStepBatch
+    out = NStepBatch(*[np.concatenate([getattr(b[0], f) for b in batches]) for f in NStepBatch._fields])     # one actor block
+    planes, ws, ws2 = plane_block(log, out.env, out.qs, out.qs2)
+    K = len(out.env)
+    assert K >= 48
+    blk = dict(planes=planes, win_s=ws, win_s2=ws2, action=out.action.astype(np.int32), reward=out.reward, done=out.done,
+               prio=np.linspace(0.1, 1.0, K).astype(np.float32))
+    buf = codec.encode(blk, codec.KIND_APEX_PLANES, actor_id=3, env_steps=99)
+    assert len(buf) == codec.apex_planes_block_bytes(K, planes.shape[0], (84, 84, 4)) < codec.apex_block_bytes(K, (84, 84, 4)) // 3
+    meta, fields = codec.layout(buf)
+    assert meta["kind"] == codec.KIND_APEX_PLANES and meta["K"] == K and meta["M"] == planes.shape[0] and meta["bytes"] == len(buf)
+    dec = codec.decode(buf)
+    for k in blk:
+        assert np.array_equal(dec[k], blk[k]), k
+    items = block_to_items(dec)                                   # the host PER (PyTorch learner path) gets full stacks back
+    for i, (s, a, r, s2, d) in enumerate(items):
+        assert np.array_equal(s, out.state[i]) and np.array_equal(s2, out.next_state[i])
+        assert a == int(out.action[i]) and r == pytest.approx(float(out.reward[i])) and d == float(out.done[i])

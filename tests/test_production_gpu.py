@@ -61,8 +61,7 @@ def test_apex_engine_batch_512_vs_fp32_autograd():
     torch.cuda.synchronize()
     B = 512
     idx = rep.idx.long()
-    s = rep.frames[:rep.capacity][idx].view(B, 84, 84, 4)
-    s2 = rep.frames[rep.capacity:][idx].view(B, 84, 84, 4)
+    s, s2 = rep.gather_stacks(idx)
     st = eng.stats()
     w = oracle.is_weights(rep.prio.cpu(), st["total_prio"], st["n_items"], st["beta"]).cuda()
     torch.backends.cudnn.allow_tf32 = False
@@ -82,13 +81,14 @@ def test_apex_engine_batch_512_vs_fp32_autograd():
     td2.loss.backward()
     rows2 = _cmp(eng.G.state_dict(), model)
     print("vs fp32 with bf16 storage:", {k: ("%.5f" % c, "%.4f" % e) for k, (c, e) in rows2.items()})
-    # measured (MI355X, r2): vs fp32 cos >= 0.99856, rel. error <= 5.4 % - all of it bf16 STORAGE of activations and
-    # activation gradients (uniform-noise frames put many pre-activations next to the ReLU threshold): with the same
-    # storage rounding in the oracle cos >= 0.99990 and the error <= 1.4 %
-    assert all(c >= 0.998 for c, _ in rows.values()), rows
-    assert all(e <= 0.06 for _, e in rows.values()), rows
-    assert all(c >= 0.9998 for c, _ in rows2.values()), rows2
-    assert all(e <= 0.02 for _, e in rows2.values()), rows2
+    # measured (MI355X, r2; random planes, s' = s moved on by 3 planes): vs fp32 cos >= 0.9957, rel. error <= 9.3 % (worst:
+    # the small val1.bias gradient; conv layers 0.998 / 6 %) - all of it bf16 STORAGE of activations and activation
+    # gradients (uniform-noise frames put many pre-activations next to the ReLU threshold): with the same storage
+    # rounding in the oracle cos >= 0.99973 and the error <= 2.3 % (conv layers: 0.9999 / 1.6 %)
+    assert all(c >= 0.995 for c, _ in rows.values()), rows
+    assert all(e <= 0.10 for _, e in rows.values()), rows
+    assert all(c >= 0.9995 for c, _ in rows2.values()), rows2
+    assert all(e <= 0.03 for _, e in rows2.values()), rows2
 
 
 @pytest.mark.parametrize("B", [64])
@@ -103,7 +103,7 @@ def test_r2d2_engine_production_shape_vs_fp32_autograd(B):
     torch.cuda.synchronize()
     T = cfg.total_len
     idx = rep.idx.long()
-    frames = rep.frames.view(rep.capacity, T, 84, 84, 4)[idx].permute(1, 0, 2, 3, 4).contiguous()
+    frames = rep.gather_stacks(idx).permute(1, 0, 2, 3, 4).contiguous()
     a, r, d = rep.act[idx].t().long(), rep.rew[idx].t(), rep.done[idx].t()
     lens = rep.length[idx].long()
     h0, c0 = rep.h0[idx], rep.c0[idx]
