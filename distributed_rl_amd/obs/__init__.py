@@ -78,11 +78,10 @@ def _fmt_x(x):
 
 
 class Metrics:
-    """Named scalar series + counters + wall-clock phase timers."""
+    """Named scalar series + wall-clock phase timers."""
 
     def __init__(self, sinks: Optional[List[Sink]] = None, min_interval: float = 0.0):
         self.sinks = sinks if sinks is not None else []
-        self.counters: Dict[str, float] = defaultdict(float)
         self.timers: Dict[str, List[float]] = defaultdict(lambda: [0.0, 0])
         self._last: Dict[str, float] = {}
         self.min_interval = min_interval
@@ -98,9 +97,6 @@ class Metrics:
     def image(self, name: str, img) -> None:
         for s in self.sinks:
             s.image(name, img)
-
-    def count(self, name: str, n: float = 1.0) -> None:
-        self.counters[name] += n
 
     @contextmanager
     def phase(self, name: str):
@@ -133,27 +129,3 @@ def make_metrics(role: str, visdom_server: str = "", jsonl_dir: str = "", quiet:
         except Exception as e:  # visdom missing or server down: metrics must never kill a worker
             sys.stderr.write("[%s] visdom sink disabled: %s\n" % (role, e))
     return Metrics(sinks, min_interval=min_interval)
-
-
-class HipEventTimer:
-    """GPU-side phase timing with HIP events (torch.cuda.Event), read back lazily."""
-
-    def __init__(self):
-        import torch
-        self._torch = torch
-        self._open: Dict[str, object] = {}
-        self._pairs: Dict[str, list] = defaultdict(list)
-
-    def start(self, name: str):
-        e = self._torch.cuda.Event(enable_timing=True)
-        e.record()
-        self._open[name] = e
-
-    def stop(self, name: str):
-        e = self._torch.cuda.Event(enable_timing=True)
-        e.record()
-        self._pairs[name].append((self._open.pop(name), e))
-
-    def report(self) -> Dict[str, float]:
-        self._torch.cuda.synchronize()
-        return {k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) for k, v in self._pairs.items()}

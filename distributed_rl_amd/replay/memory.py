@@ -1,10 +1,9 @@
-"""Host replay containers (reference: libs/replay_memory.py:6-81).
+"""Host prioritized replay of the PyTorch learner path (reference: libs/replay_memory.py:51-81).
 
-* :class:`ReplayMemory` — bounded uniform buffer, the actor-side staging buffer (replay_memory.py:29-48).
-* :class:`PrioritizedMemory` — items + sum-tree with the reference's *soft capacity*: it may grow
-  past ``capacity`` until :meth:`remove_to_fit` pops the oldest overflow (replay_memory.py:70-75).
-* :class:`CompressedDeque` / :func:`generate_deque` — kept for API parity (replay_memory.py:6-27);
-  compression is opt-in and irrelevant for uint8 frames.
+:class:`PrioritizedMemory` — items + sum-tree with the reference's *soft capacity*: it may grow past ``capacity`` until
+:meth:`remove_to_fit` pops the oldest overflow (replay_memory.py:70-75). The reference's uniform ``ReplayMemory`` (the
+actors' staging buffer) and its lz4 ``CompressedDeque`` have no counterpart here: actors stage in preallocated arrays
+(runtime/actor.py) and frames travel as raw uint8 planes.
 
 Indices handed out by ``PrioritizedMemory.sample`` are *logical* (0 = oldest) like the reference's,
 and in addition every item carries a monotonically increasing id; :meth:`update_priorities`
@@ -13,53 +12,12 @@ wrong item (the generation-tag invariant of SURVEY §5.2).
 """
 from __future__ import annotations
 
-import random
-from collections import deque
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .. import utils
 from .sumtree import SumTree
-
-
-class CompressedDeque(deque):
-    def __iter__(self):
-        return (utils.loads(v) for v in super().__iter__())
-
-    def append(self, data):
-        super().append(utils.dumps(data))
-
-    def extend(self, datum):
-        for d in datum:
-            self.append(d)
-
-    def __getitem__(self, idx):
-        return utils.loads(super().__getitem__(idx))
-
-
-def generate_deque(use_compress: bool = False, capacity: Optional[int] = None):
-    return CompressedDeque(maxlen=capacity) if use_compress else deque(maxlen=capacity)
-
-
-class ReplayMemory:
-    def __init__(self, capacity: int, use_compress: bool = False):
-        self.memory = generate_deque(use_compress, capacity)
-
-    def push(self, data) -> None:
-        self.memory.append(data)
-
-    def sample(self, batch_size: int):
-        return random.sample(list(self.memory), batch_size)
-
-    def clear(self) -> None:
-        self.memory.clear()
-
-    def __getitem__(self, idx):
-        return self.memory[idx]
-
-    def __len__(self) -> int:
-        return len(self.memory)
 
 
 class PrioritizedMemory:

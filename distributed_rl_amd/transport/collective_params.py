@@ -95,12 +95,6 @@ class CollectiveParams(ParamChannel):
                 return None
             return self._v, self._cur.detach().cpu().numpy().copy()
 
-    def pull_device(self, have_version: int = 0) -> Optional[Tuple[int, torch.Tensor]]:
-        """Like ``pull`` but hands out a device tensor (engines load it with ``load_flat`` without a host copy)."""
-        with self._lock:
-            if self._v <= have_version:
-                return None
-            return self._v, self._cur.clone()
 
     def version(self) -> int:
         return self._v

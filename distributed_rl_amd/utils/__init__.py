@@ -41,9 +41,6 @@ class Transition(namedtuple("Transition", ("state", "action", "reward", "next_st
 Sequence = namedtuple("Sequence", ("transitions", "recurrent_state"))
 
 
-def outsize(x, f, p=0, s=1):
-    """Conv output size helper (utils.py:21-24); integer arithmetic, unlike the reference's float."""
-    return ((x[0] - f + 2 * p) // s + 1, (x[1] - f + 2 * p) // s + 1)
 
 
 def preprocess(img: np.ndarray, shape: Optional[_Seq[int]] = None, gray: bool = False,
@@ -144,13 +141,4 @@ def nstep_return(rewards, gamma: float, reference_order: bool = False) -> float:
     return float(sum(gamma ** i * float(r) for i, r in enumerate(rewards)))
 
 
-def chw_to_hwc_u8(frames: np.ndarray) -> np.ndarray:
-    """(…,C,H,W) → (…,H,W,C) contiguous uint8: the replay store / conv1 layout."""
-    return np.ascontiguousarray(np.moveaxis(frames, -3, -1))
 
-
-def to_u8(frames: np.ndarray) -> np.ndarray:
-    """float frames in [0,1] → uint8 (round to nearest)."""
-    if frames.dtype == np.uint8:
-        return frames
-    return np.clip(np.rint(frames * 255.0), 0, 255).astype(np.uint8)

@@ -1,25 +1,10 @@
-"""Sum-tree / PrioritizedMemory / ReplayMemory semantics (reference: libs/sumtree.py, libs/replay_memory.py;
+"""Sum-tree / PrioritizedMemory semantics (reference: libs/sumtree.py, libs/replay_memory.py;
 untested upstream — SURVEY §4)."""
 import numpy as np
 import pytest
 
-from distributed_rl_amd.replay.memory import CompressedDeque, PrioritizedMemory, ReplayMemory, generate_deque
+from distributed_rl_amd.replay.memory import PrioritizedMemory
 from distributed_rl_amd.replay.sumtree import SumTree
-
-
-def test_compressed_deque():
-    # the intent of reference tests/libs/test_replay_memory.py:9-29 against the current signature
-    dq = generate_deque(True, 10)
-    assert isinstance(dq, CompressedDeque)
-    dq.append(1)
-    assert len(dq) == 1
-    dq.extend(range(9))
-    assert len(dq) == 10
-    dq.append(10)
-    assert len(dq) == 10 and dq[-1] == 10
-    dq = generate_deque(True)
-    dq.extend(range(11))
-    assert len(dq) == 11 and list(dq) == list(range(11))
 
 
 def test_sumtree_deque_semantics():
@@ -100,14 +85,3 @@ def test_prioritized_memory_compress():
     m.push([("a", i) for i in range(4)], [1, 2, 3, 4])
     items, _, idxs = m.sample(3)
     assert all(it == ("a", ix) for it, ix in zip(items, idxs))
-
-
-def test_replay_memory_uniform():
-    r = ReplayMemory(5)
-    for i in range(8):
-        r.push(i)
-    assert len(r) == 5 and r[0] == 3
-    s = r.sample(5)
-    assert sorted(s) == [3, 4, 5, 6, 7]                  # without replacement (replay_memory.py:38-39)
-    r.clear()
-    assert len(r) == 0
