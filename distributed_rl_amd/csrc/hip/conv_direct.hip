@@ -1,19 +1,14 @@
-// Direct (barrier-free) forward convolutions for the Nature-CNN torso on gfx950 (forward).
+// Direct (barrier-free) forward convolution conv1 of the Nature-CNN torso on gfx950 (forward).
 //
-// The K ordering (kh, kw, c) of the NHWC implicit GEMM has a property the generic LDS-tiled kernel in gemm.hip does not
-// use: one MFMA k-step (32 contraction elements) is a CONTIGUOUS run of the input —
-//     conv1: one patch row  = 8 px x 4 ch u8   = 32 bytes,
-//     conv2: one patch pixel = 32 ch bf16       = 64 bytes,
-//     conv3: half a patch pixel (64 ch bf16)    = 64 bytes,
-// and the 8 consecutive k a lane needs for its 16x16x32 operand fragment are one 8-byte (u8) / 16-byte (bf16) global
-// load. So the activation operand goes global -> VGPR directly in MFMA fragment layout: no LDS staging, no
-// __syncthreads, no shared K-loop between waves. Every wave walks its own run of 16- or 32-row output tiles with the
-// next tile's loads in flight, and the weights are resident for the life of the wave:
-//     conv1: all 32x256 weights live in 64 VGPRs per lane;
-//     conv2/3: 64x512 / 64x576 weights are copied once per workgroup into LDS in fragment order (conflict-free
-//              ds_read_b128), then only read.
-// Operands are passed swapped (acc = mfma(W, X)) so a lane ends up with 4 consecutive output channels of one output
-// pixel: bias + ReLU + v_cvt_pk_bf16_f32 and an 8-byte store.
+// One MFMA k-step (32 contraction elements) of conv1 is a CONTIGUOUS run of the input: one patch row = 8 px x 4 ch u8 =
+// 32 bytes of an HWC stack, or 8 px of one plane x 4 patch rows of a plane store; the 8 consecutive k a lane needs for
+// its 16x16x32 operand fragment are one 8-byte global load. So the activation operand goes global -> VGPR directly in
+// MFMA fragment layout: no LDS staging, no __syncthreads, no shared K-loop between waves. Every wave walks its own run
+// of 16-row output tiles with the next tile's loads in flight, and all 32x256 weights live in 64 VGPRs per lane for the
+// life of the wave. Operands are passed swapped (acc = mfma(W, X)) so a lane ends up with consecutive output channels
+// of one output pixel: bias + ReLU + v_cvt_pk_bf16_f32 and a 16-byte store.
+// (conv2 / conv3 had the same form with the weights in LDS; 21.3 / 16.5 us at 1024 frames against 17.0 / 13.4 us for the
+// LDS-tiled implicit GEMM, and the LDS-halo kernels of conv_halo.hip beat both: it is gone.)
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -92,17 +87,15 @@ struct Conv1Net {
     int M, per;
 };
 
-// PAIR: the blocks of the SECOND range [nblk1, gridDim.x) also multiply every tile with a second weight set, n3 (weights /
-// bias / output only; the frames are those of n2): the tile is loaded and converted once for both networks. R2D2 learner:
-// online + target over one sequence batch (nblk1 = 0); Ape-X learner: online on s in the first range, online AND target
-// on s' in the second.
-// PAIR = 1: every block is a pair block (primary network n1, second weight set n3; decided at compile time);
-// PAIR = 2: the blocks of the second range are.
+// PAIR = 1: every block also multiplies its tiles with a second weight set, n3 (weights / bias / output only; the frames
+// are those of n1): a tile is loaded and converted once for both networks. R2D2 learner: online + target over one
+// sequence batch. (A form for the Ape-X learner - online on s, online AND target on s' - measured no better than the
+// two-network launch below and is gone.)
 template <bool OFF, int PAIR = 0>
 __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, Conv1Net n3, int nblk1) {
     static_assert(!PAIR || DRL_CONV1_F16, "the two-weight-set form exists for the f16 path only");
     const bool second = PAIR != 1 && (int)blockIdx.x >= nblk1;         // block-uniform
-    const bool pair_blk = PAIR == 1 || (PAIR == 2 && second);
+    constexpr bool pair_blk = PAIR == 1;
     const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
     const bf16_t* __restrict__ w = second ? n2.w : n1.w;
     const float* __restrict__ bias = second ? n2.bias : n1.bias;
@@ -258,99 +251,6 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
     if (tile < t1) body(bufa, bufb, tile);  // odd tail
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// conv2 / conv3: bf16 NHWC -> bf16 NHWC, 64 output channels, weights resident in LDS in fragment order.
-// A k-step is 64 contiguous input bytes (C = 32: one patch pixel; C = 64: half a patch pixel). Each wave owns 32-row
-// tiles (2 MFMA row blocks share every weight fragment read from LDS) and runs KS phases (one patch row each) with
-// the next phase's loads in flight.
-// ---------------------------------------------------------------------------------------------------------------
-template <int H, int W, int C, int KS, int S, int RT, int NWV>
-__global__ __launch_bounds__(NWV * 64, 2) void k_conv_direct(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                            const float* __restrict__ bias, bf16_t* __restrict__ out,
-                                                            int M, int per) {
-    constexpr int OH = (H - KS) / S + 1, OW = (W - KS) / S + 1, K = KS * KS * C, NS = K / 32;   // NS k-steps
-    constexpr int SPR = KS * C / 32;          // k-steps per patch row (conv2: 4, conv3: 6)
-    constexpr int TR = RT * 16;               // rows per wave tile
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                            // 4 * NS * 1 KB
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
-    // weights -> LDS, fragment order: frag (t, s) holds for lane l the 8 k of W[t*16 + l%16][s*32 + (l/16)*8 ..]
-    for (int i = tid; i < 4 * NS * 64; i += NWV * 64) {
-        const int l = i & 63, f = i >> 6, s = f % NS, t = f / NS;
-        *reinterpret_cast<uint4*>(smem + (size_t)i * 16) =
-            *reinterpret_cast<const uint4*>(w + (size_t)(t * 16 + (l & 15)) * K + s * 32 + (l >> 4) * 8);
-    }
-    __syncthreads();                          // the only barrier: weights are read-only from here on
-    const int ntiles = (M + TR - 1) / TR;
-    // every wave owns `per` CONSECUTIVE tiles: neighbouring output pixels share input pixels, so the re-reads hit L1/L2
-    const int t0 = (blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(tid >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
-    float4 b4[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + t * 16 + g * 4);
-
-    // element offset of patch (row m) origin + this lane's 8-channel group
-    auto base_of = [&](int tile, int sub) -> unsigned {
-        const int m = min(min(tile, ntiles - 1) * TR + sub * 16 + r, M - 1);
-        const int b = m / (OH * OW), rem = m - b * (OH * OW), oy = rem / OW, ox = rem - oy * OW;
-        return (unsigned)(((b * H + oy * S) * W + ox * S) * C + g * 8);
-    };
-    auto load_row = [&](uint4 (&dst)[RT][SPR], const unsigned (&base)[RT], int ky) {
-#pragma unroll
-        for (int u = 0; u < RT; ++u)
-#pragma unroll
-            for (int j = 0; j < SPR; ++j) dst[u][j] = *reinterpret_cast<const uint4*>(x + base[u] + ky * (W * C) + j * 32);
-    };
-    unsigned base[RT], nbase[RT];
-#pragma unroll
-    for (int u = 0; u < RT; ++u) base[u] = base_of(t0, u);
-    uint4 cur[RT][SPR], nxt[RT][SPR];
-    load_row(cur, base, 0);
-    for (int tile = t0; tile < t1; ++tile) {
-#pragma unroll
-        for (int u = 0; u < RT; ++u) nbase[u] = base_of(tile + 1, u);
-        f32x4 acc[RT][4];
-#pragma unroll
-        for (int u = 0; u < RT; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            // compiler fence: the weight fragments are loop-invariant LDS reads and LICM would hoist all 4*NS of them
-            // (256+ VGPRs, spills) out of the tile loop; they must be re-read from LDS in every phase
-            asm volatile("" ::: "memory");
-            if (ky + 1 < KS) load_row(nxt, base, ky + 1);
-            else load_row(nxt, nbase, 0);                         // first patch row of the wave's next tile
-#pragma unroll
-            for (int j = 0; j < SPR; ++j) {
-                const int s = ky * SPR + j;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(t * NS + s) * 64 + lane) * 16);
-#pragma unroll
-                    for (int u = 0; u < RT; ++u) acc[u][t] = mfma16(wf, __builtin_bit_cast(bf16x8, cur[u][j]), acc[u][t]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < RT; ++u)
-#pragma unroll
-                for (int j = 0; j < SPR; ++j) cur[u][j] = nxt[u][j];
-        }
-#pragma unroll
-        for (int u = 0; u < RT; ++u) {
-            const int m = tile * TR + u * 16 + r;
-            if (m < M) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t lo = pack_bf2(fmaxf(acc[u][t][0] + b4[t].x, 0.f), fmaxf(acc[u][t][1] + b4[t].y, 0.f));
-                    const uint32_t hi = pack_bf2(fmaxf(acc[u][t][2] + b4[t].z, 0.f), fmaxf(acc[u][t][3] + b4[t].w, 0.f));
-                    *reinterpret_cast<uint2*>(out + (long long)m * 64 + t * 16 + g * 4) = make_uint2(lo, hi);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < RT; ++u) base[u] = nbase[u];
-    }
-}
-
 // tiles per wave so that at most `slots` waves are needed; returns the grid in *grid
 static int plan(int ntiles, int slots, int nwv, int* grid) {
     int per = (ntiles + slots - 1) / slots;
@@ -359,48 +259,16 @@ static int plan(int ntiles, int slots, int nwv, int* grid) {
     return per;
 }
 
-template <int H, int W, int C, int KS, int S, int RT, int NWV>
-static void launch_direct(const void* x, const void* w, const float* bias, void* out, int M, hipStream_t s) {
-    constexpr int LDS = 4 * (KS * KS * C / 32) * 1024;
-    auto kern = k_conv_direct<H, W, C, KS, S, RT, NWV>;
-    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
-    (void)once;
-    int grid;
-    const int per = plan((M + RT * 16 - 1) / (RT * 16), 256 * 2 * NWV, NWV, &grid);   // 2 workgroups resident per CU
-    kern<<<grid, NWV * 64, LDS, s>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)out, M, per);
-}
-
-// layer 1: x u8 (+ optional per-frame byte offsets) ; layers 2/3: x bf16 NHWC. out bf16 NHWC, bias + ReLU fused.
-// variant (layers 2/3): 0 = 32-row tiles, 4 waves | 1 = 16-row tiles, 8 waves | 2 = 32-row, 8 waves | 3 = 16-row, 4 waves
-DRL_API int drl_conv_fwd_direct(int layer, const void* x, const void* w, const float* bias, void* out, int frames,
-                                const long long* frame_off, int variant, hipStream_t s) {
+// conv1: x u8 HWC stacks, or a plane store + per-frame byte offsets. out bf16 NHWC, bias + ReLU fused.
+DRL_API int drl_conv1_fwd(const void* x, const void* w, const float* bias, void* out, int frames, const long long* frame_off,
+                          hipStream_t s) {
     if (frames <= 0) return -1;
-    if (layer == 1) {
-        const int M = frames * 400;
-        int grid;
-        const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
-        const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
-        if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
-        else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
-    } else if (layer == 2) {
-        if ((long long)frames * 20 * 20 * 32 >= (1LL << 32)) return -8;
-        const int M = frames * 81;
-        switch (variant) {
-            case 0: launch_direct<20, 20, 32, 4, 2, 2, 4>(x, w, bias, out, M, s); break;
-            case 1: launch_direct<20, 20, 32, 4, 2, 1, 8>(x, w, bias, out, M, s); break;
-            case 2: launch_direct<20, 20, 32, 4, 2, 2, 8>(x, w, bias, out, M, s); break;
-            default: launch_direct<20, 20, 32, 4, 2, 1, 4>(x, w, bias, out, M, s); break;
-        }
-    } else if (layer == 3) {
-        if ((long long)frames * 9 * 9 * 64 >= (1LL << 32)) return -8;
-        const int M = frames * 49;
-        switch (variant) {
-            case 0: launch_direct<9, 9, 64, 3, 1, 2, 4>(x, w, bias, out, M, s); break;
-            case 1: launch_direct<9, 9, 64, 3, 1, 1, 8>(x, w, bias, out, M, s); break;
-            case 2: launch_direct<9, 9, 64, 3, 1, 2, 8>(x, w, bias, out, M, s); break;
-            default: launch_direct<9, 9, 64, 3, 1, 1, 4>(x, w, bias, out, M, s); break;
-        }
-    } else return -1;
+    const int M = frames * 400;
+    int grid;
+    const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
+    const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
+    if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
+    else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
     return (int)hipGetLastError();
 }
 
@@ -432,30 +300,6 @@ DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int fr
     const Conv1Net n1{frame_off, (const bf16_t*)w1, bias1, (bf16_t*)out1, M, per};
     const Conv1Net n3{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
     k_conv1_direct<true, 1><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n3, grid);
-    return (int)hipGetLastError();
-#else
-    return -1;
-#endif
-}
-
-// Ape-X learner: network 1 on frames1 (through frame_off1 -> out1a) AND on frames2 (frame_off2 -> out1b), network 2 on
-// frames2 only (-> out2): the blocks of the second range multiply every tile of frames2 with both weight sets.
-DRL_API int drl_conv1_fwd_apex(const void* x, const long long* frame_off1, int frames1, const long long* frame_off2, int frames2,
-                               const void* w1, const float* bias1, void* out1a, void* out1b, const void* w2, const float* bias2,
-                               void* out2, hipStream_t s) {
-#if DRL_CONV1_F16
-    if (frames1 <= 0 || frames2 <= 0 || !frame_off1 || !frame_off2) return -1;
-    int g1, g2;
-    const int slots = 256 * DRL_CONV1_WAVES_PER_CU;
-    const int M1 = frames1 * 400, M2 = frames2 * 400;
-    // a pair tile costs about 1.6 single tiles (two MFMA sets, one load + conversion): split the wave slots accordingly
-    const long long wgt1 = 10LL * M1, wgt2 = 16LL * M2;
-    const int s1 = (int)((long long)slots * wgt1 / (wgt1 + wgt2)), s2 = slots - s1;
-    const int per1 = plan((M1 + 15) / 16, s1 > 0 ? s1 : 1, 4, &g1), per2 = plan((M2 + 15) / 16, s2 > 0 ? s2 : 1, 4, &g2);
-    const Conv1Net n1{frame_off1, (const bf16_t*)w1, bias1, (bf16_t*)out1a, M1, per1};
-    const Conv1Net n2{frame_off2, (const bf16_t*)w1, bias1, (bf16_t*)out1b, M2, per2};
-    const Conv1Net n3{frame_off2, (const bf16_t*)w2, bias2, (bf16_t*)out2, M2, per2};
-    k_conv1_direct<true, 2><<<g1 + g2, 256, 0, s>>>((const uint8_t*)x, n1, n2, n3, g1);
     return (int)hipGetLastError();
 #else
     return -1;

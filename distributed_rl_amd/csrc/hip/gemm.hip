@@ -913,20 +913,6 @@ DRL_API int drl_conv_wgrad(int layer, const void* x, const long long* frame_off,
     return -1;
 }
 
-// ---- conv input gradient, step 1: dCol[M][K] = dY[M][Cout] . W[Cout][K]   (bf16; col2im gathers it, conv_bwd.hip) ----
-DRL_API int drl_conv_dcol(int layer, const void* dy, int frames, const void* w, void* dcol, hipStream_t s) {
-    if (layer == 2) {
-        const int M = frames * Conv2Op::OH * Conv2Op::OW;
-        DenseOp A{(const bf16_t*)dy, 64, M}, B{(const bf16_t*)w, Conv2Op::K, 64};
-        return launch<128, 64, 64, 2, 2, false, true, 2>(A, B, M, Conv2Op::K, 64, 1, make_epi(dcol, Conv2Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
-    } else if (layer == 3) {
-        const int M = frames * Conv3Op::OH * Conv3Op::OW;
-        DenseOp A{(const bf16_t*)dy, 64, M}, B{(const bf16_t*)w, Conv3Op::K, 64};
-        return launch<128, 64, 64, 2, 2, false, true, 2>(A, B, M, Conv3Op::K, 64, 1, make_epi(dcol, Conv3Op::K, nullptr, nullptr, 0, 1.0f, 0), s);
-    }
-    return -1;
-}
-
 // ---- conv input gradient, implicit form: dX = relu'(act_in) * dgrad(dY, W), one launch, no dCol / col2im ----
 // layer 2: dY [frames][9][9][64], W [64][4][4][32] -> dX [frames][20][20][32];  layer 3: dY [frames][7][7][64],
 // W [64][3][3][64] -> dX [frames][9][9][64]. act_in = forward input of the layer (ReLU mask), same shape as dX.

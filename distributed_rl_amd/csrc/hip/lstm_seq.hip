@@ -9,8 +9,8 @@
 //     wave w owns batch rows [16w, 16w+16). acc = mfma(W, h): a lane ends with the 4 gates of one unit per MFMA tile, and
 //     the weight rows are permuted so that its 4 tiles are 4 CONSECUTIVE units: cell update in registers (c never leaves
 //     them), 8-byte h stores, 16-byte c stores, 32-byte gate stores, 64-byte xg loads.
-//   * Between steps the workgroups of one network meet at a counter in global memory (write-through hand-off, see
-//     grid_wait / grid_arrive below). Every spin is BOUNDED: if it expires an error flag is raised and the kernel stops
+//   * Between steps the workgroups of one network meet at arrival flags in global memory (write-through hand-off, see
+//     grid_wait_fl / grid_arrive_fl below). Every spin is BOUNDED: if it expires an error flag is raised and the kernel stops
 //     waiting (wrong numbers, reported by the host wrapper, but never a hung GPU). 32-64 workgroups of 256 threads /
 //     64 KB LDS are always co-resident on 256 CUs.
 #include "common.h"
@@ -23,18 +23,6 @@ __device__ __forceinline__ f32x4 mfma16_(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-struct LstmSeqNet {
-    const float* xg;      // [T][M][4H]  input projection + both biases (f32)
-    const bf16_t* w_hh;   // [4H][H]     gate-interleaved rows n = 4*unit + gate
-    bf16_t* hs;           // [T+1][M][H] hs[0] = initial state (in), hs[t+1] = h after step t (out)
-    float* cs;            // [T+1][M][H] cs[0] = initial state (in), cs[t+1] = c after step t (out)
-    bf16_t* gates;        // [T][M][4H]  post-activation (i,f,g,o) for the backward pass, or nullptr
-    int* sync;            // arrival counter of this network (zeroed by the host wrapper before the launch)
-};
-
-#ifndef DRL_LSTM_B128_LOADS
-#define DRL_LSTM_B128_LOADS 1
-#endif
 // bound of every inter-workgroup poll (iterations of load + s_sleep); a device global so that a test can shrink it and
 // drive the give-up path for real (drl_lstm_set_spin_limit)
 __device__ int g_spin_limit = 1 << 17;
@@ -44,120 +32,13 @@ typedef unsigned long long u64_t;
 
 // Hand-off of h_t between the workgroups of one network, write-through form (MI355X: per-CU L1 and per-XCD L2 are not
 // coherent inside a launch): every h store is an agent-scope 8-byte atomic store (global_store_dwordx2 sc1), every
-// storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to the counter; the consumer's lane 0
-// polls the counter with sc1 loads, workgroup barrier, and EVERY load of h is an agent-scope 8-byte atomic load
-// (global_load_dwordx2 sc1, bypasses L1) - so neither an L2 write-back nor an L1 invalidate fence is paid per step
-// (the fence form measured 9.4 us per step, no better than one launch per step).
-__device__ __forceinline__ void grid_wait(int* sync, int target, int* err, int* s_dead) {
-    if (threadIdx.x == 0 && !*s_dead) {
-        int it = 0;
-        while (__hip_atomic_load(sync, RLX_AGENT) < target) {
-            if (++it > SPIN_LIMIT) { atomicExch(err, 1); *s_dead = 1; break; }   // bounded: never hang the GPU
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the h loads below the poll
-}
-__device__ __forceinline__ void grid_arrive(int* sync) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its sc1 stores ...
-    __syncthreads();                                          // ... before the one lane that signals for all of them
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync, 1, RLX_AGENT);
-}
-
-template <int HD>
-__global__ __launch_bounds__(256) void k_lstm_seq_fwd(LstmSeqNet n0, LstmSeqNet n1, int T, int M, int* err) {
-    constexpr int NWG = 4 * HD / 64, NKS = HD / 32;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];       // 4 * NKS KB: W slice in fragment order
-    const int net = blockIdx.x / NWG, wg = blockIdx.x % NWG;
-    const LstmSeqNet a = net ? n1 : n0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g4 = lane >> 4;
-    // fragment (nt, ks): lane l holds W[n][ks*32 + (l/16)*8 ..], MFMA row i = l%16 -> unit 4*(i/4) + nt, gate i%4
-    for (int i = tid; i < 4 * NKS * 64; i += 256) {
-        const int l = i & 63, f = i >> 6, ks = f % NKS, nt = f / NKS, ii = l & 15;
-        const int n = 64 * wg + 4 * (4 * (ii >> 2) + nt) + (ii & 3);
-        *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = *reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + ks * 32 + (l >> 4) * 8);
-    }
-    __syncthreads();
-    const bool active = wave * 16 < M;
-    const int m = min(wave * 16 + r, M - 1);
-    const int u0 = 16 * wg + 4 * g4;                 // this lane owns units u0 .. u0+3 of row m
-    float c[4];
-    {
-        const float4 c0 = *reinterpret_cast<const float4*>(a.cs + (size_t)m * HD + u0);
-        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
-    }
-#if DRL_LSTM_B128_LOADS
-    const auto hs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hs, 0, (int)((size_t)(T + 1) * M * HD * sizeof(bf16_t)), 0x00020000);
-#endif
-    __shared__ int s_dead;
-    if (tid == 0) s_dead = 0;
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        // input projection of this step: independent of the recurrence, issued before the wait
-        float4 xq[4];
-        const float* xrow = a.xg + ((size_t)t * M + m) * (4 * HD) + 4 * u0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const float4*>(xrow + 4 * q);
-        if (t > 0) grid_wait(a.sync, NWG * t, err, &s_dead);
-        bf16x8 hf[NKS];
-#if DRL_LSTM_B128_LOADS
-        // ONE 16-byte sc1 buffer load per fragment (aux 16 = sc1: served by L2 / memory, never by this CU's L1)
-        const unsigned hoff = (unsigned)((((size_t)t * M + m) * HD + g4 * 8) * sizeof(bf16_t));
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hs_rsrc, hoff + ks * 64, 0, 16);
-            hf[ks] = __builtin_bit_cast(bf16x8, v);
-        }
-#else
-        u64_t* hrow = reinterpret_cast<u64_t*>(a.hs + ((size_t)t * M + m) * HD + g4 * 8);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {                        // 2 x global_load_dwordx2 sc1 per fragment
-            const u64_t lo = __hip_atomic_load(hrow + ks * 8, RLX_AGENT), hi = __hip_atomic_load(hrow + ks * 8 + 1, RLX_AGENT);
-            hf[ks] = __builtin_bit_cast(bf16x8, make_ulonglong2(lo, hi));
-        }
-#endif
-        f32x4 acc[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(nt * NKS + ks) * 64 + lane) * 16);
-                acc[nt] = mfma16_(wf, hf[ks], acc[nt]);
-            }
-        float h[4];
-        uint32_t gp[8];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const float ig = sigm_(acc[nt][0] + xq[nt].x), fg = sigm_(acc[nt][1] + xq[nt].y);
-            const float gg = tanh_(acc[nt][2] + xq[nt].z), og = sigm_(acc[nt][3] + xq[nt].w);
-            c[nt] = fg * c[nt] + ig * gg;
-            h[nt] = og * tanh_(c[nt]);
-            gp[2 * nt] = pack_bf2(ig, fg);
-            gp[2 * nt + 1] = pack_bf2(gg, og);
-        }
-        if (active) {
-            const size_t o = ((size_t)(t + 1) * M + m) * HD + u0;
-            __hip_atomic_store(reinterpret_cast<u64_t*>(a.hs + o),
-                               (u64_t)pack_bf2(h[0], h[1]) | ((u64_t)pack_bf2(h[2], h[3]) << 32), RLX_AGENT);   // sc1 store
-            *reinterpret_cast<float4*>(a.cs + o) = make_float4(c[0], c[1], c[2], c[3]);
-            if (a.gates) {
-                uint4* gout = reinterpret_cast<uint4*>(a.gates + ((size_t)t * M + m) * (4 * HD) + 4 * u0);
-                gout[0] = make_uint4(gp[0], gp[1], gp[2], gp[3]);
-                gout[1] = make_uint4(gp[4], gp[5], gp[6], gp[7]);
-            }
-        }
-        if (t + 1 < T) grid_arrive(a.sync);
-    }
-}
-
-// ---- coalesced exchange form --------------------------------------------------------------------------------------
-// In the form above a wave's h load instruction touches 16 rows x 64 bytes: half of 16 different 128-byte lines, and the
-// other halves are fetched again by the next instruction - sc1 loads are not kept by any cache on the way. Here h_t
-// travels through an exchange buffer laid out in CONSUMER order, [parity][wave][ks][lane][8 x bf16]: one load instruction
+// storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane signals; the consumer polls with sc1 loads,
+// workgroup barrier, and EVERY load of h is an agent-scope load (sc1, bypasses L1) - so neither an L2 write-back nor an
+// L1 invalidate fence is paid per step (the fence form measured 9.4 us per step, no better than one launch per step).
+// A first form handed h over in its plain [M][H] layout with one arrival counter per network: there a wave's load
+// instruction touches 16 rows x 64 bytes, half of 16 different 128-byte lines, and the other halves are fetched again by
+// the next instruction (sc1 loads are kept by no cache on the way): 5.5 us per step. What runs is the coalesced exchange
+// form (4.6 us per step): h_t travels through an exchange buffer laid out in CONSUMER order, [parity][wave][ks][lane][8 x bf16]: one load instruction
 // of a wave is one contiguous kilobyte (8 whole lines, each fetched once). Producers scatter their 8-byte pieces into it
 // (write-through stores as before); hs keeps its plain layout for the kernels outside (ordinary stores, nobody inside the
 // launch reads them). Same counter protocol. Two parity slots: slot (t+1)&1 last held h_{t-1}, which every workgroup had
@@ -306,22 +187,6 @@ DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, floa
     static bool once = (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
     (void)once;
     k0<<<n_nets * (4 * 512 / 64), 256, LDS, s>>>(a, b, T, M, err);
-    return (int)hipGetLastError();
-}
-
-// Runs T steps for one (n_nets = 1) or two networks. sync: 2 ints, err: 1 int (device memory; zeroed here).
-DRL_API int drl_lstm_seq_fwd(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, const float* xg1,
-                             const void* w1, void* hs1, float* cs1, void* gates1, int n_nets, int T, int M, int H, int* sync,
-                             int* err, hipStream_t s) {
-    if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2) return -1;
-    if (hipMemsetAsync(sync, 0, 2 * sizeof(int), s) != hipSuccess) return -2;
-    LstmSeqNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, sync};
-    LstmSeqNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, sync + 1};
-    constexpr int LDS = 4 * (512 / 32) * 1024;
-    auto kern = k_lstm_seq_fwd<512>;
-    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
-    (void)once;
-    kern<<<n_nets * (4 * 512 / 64), 256, LDS, s>>>(a, b, T, M, err);
     return (int)hipGetLastError();
 }
 

@@ -7,7 +7,8 @@ between PER sampling and the priority write-back:
   online  torso on [s ; s'] (2B frames, conv1 reads uint8 straight from the replay store) → FC1 → head → Q
   target  torso on s' → Q_target
   fused TD (IS weights, double-DQN target, Huber, loss, dL/dQ, new priorities)
-  backward: head → FC1 (dW, db, dX·ReLU') → conv3/2/1 (wgrad split-K, bias colsum, dCol GEMM + col2im·ReLU')
+  backward: head + FC1 in one launch (dW, db, dX·ReLU') → conv3, conv2, conv1: one launch each (dX·ReLU' as a convolution
+  of dY with the flipped weights + split-K dW + bias column sum; from 1024 frames dX runs in the LDS-halo kernel)
   [RCCL all-reduce of the flat gradient buffer when world_size > 1]
   global-norm clip + RMSprop + bf16 re-cast (2 launches over the flat buffers)
   sum-tree priority write-back → step_end → (every target_update steps) target ← online (one flat copy)
@@ -30,7 +31,7 @@ from ..ops import hip as H
 from ..replay.device_per import DevicePER
 from .guard import StepGuard
 from .shard import ShardedIS
-from .streams import ForkJoin, capture_graph
+from .streams import capture_graph
 
 
 class TorsoBuffers:
@@ -62,18 +63,13 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 
 def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
-                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers,
-                       shared_tail: bool = False, prep=None) -> None:
+                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers, prep=None) -> None:
     """Forward of TWO networks (online on n1 frames, target on n2 frames), 5 launches in total: each layer of both networks
-    is one launch, so the learner's step needs no second stream (no fork / join) for the target network."""
-    if shared_tail and n1 == 2 * n2:
-        # the second network's frames ARE the second half of the first network's (online on [s ; s'], target on s'):
-        # those tiles are read and converted once and multiplied with both weight sets
-        H.conv1_fwd_apex(x_u8, off1[:n2], n2, off2, n2, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[:n2], b1.act1[n2:],
-                         wb2.view("conv1.w"), wf2.view("conv1.b"), b2.act1)
-    else:
-        H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
-                        wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
+    is one launch, so the learner's step needs no second stream (no fork / join) for the target network. (Sharing the s'
+    tiles of conv1 between the two networks inside that launch was measured and dropped: 0.2465 vs 0.2400 ms per step, the
+    heavier pair blocks set the launch's registers and its tail.)"""
+    H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
+                    wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
         H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
                         getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst),
@@ -86,8 +82,7 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
 
 class ApexEngine(ShardedIS):
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
-                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
-                 overlap: bool = True):
+                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -116,9 +111,7 @@ class ApexEngine(ShardedIS):
         self.new_prio = torch.zeros(B, device=dev)
         self.dh = torch.zeros(B, 1024, **bf)
         self.d3 = torch.zeros(B * 49, 64, **bf)          # d conv3 pre-activation
-        self.dcol3 = torch.zeros(B * 49, 576, **bf)
         self.d2 = torch.zeros(B * 81, 64, **bf)          # d conv2 pre-activation
-        self.dcol2 = torch.zeros(B * 81, 512, **bf)
         self.d1 = torch.zeros(B * 400, 32, **bf)         # d conv1 pre-activation
         # input gradients of conv3 / conv2 through the LDS-halo kernel: flipped / transposed weight copies, rewritten by
         # extra workgroups of every step's conv2 forward launch (ops.hip.conv_halo_fwd(prep=...))
@@ -134,21 +127,12 @@ class ApexEngine(ShardedIS):
         self.use_graph = use_graph
         self._init_shard(replay, dist, dev)              # self.n_is: device scalar N_global / world (engine/shard.py)
         self.overlap_comm = os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
-        self.fused_bwd = os.environ.get("DRL_FUSED_BWD", "1") != "0"     # horizontally fused backward launches
-        # software-pipelined sampler (needs the fused path: step_end must have run before the optimizer launch)
-        self.presample = self.fused_bwd and B % 4 == 0 and os.environ.get("DRL_PRESAMPLE", "1") != "0"
+        # software-pipelined sampler: the next step's PER batch is drawn inside this step's conv1 backward launch
+        self.presample = B % 4 == 0 and os.environ.get("DRL_PRESAMPLE", "1") != "0"
         if self.presample:
             replay._next_buffers()                                        # allocate now, never inside a graph capture
-        self.dual_fwd = os.environ.get("DRL_DUAL_FWD", "1") != "0"       # online + target forward as one launch per layer
-        # s' read + converted once for the online and the target conv1 (two weight sets per tile in part of the launch):
-        # measured SLOWER here (0.2465 vs 0.2400 ms: the heavier pair blocks set the launch's registers and its tail), off
-        self.conv1_pair = os.environ.get("DRL_APEX_CONV1_PAIR", "0") != "0"
         self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
-        # side HIP streams: the target forward and the weight-gradient kernels are independent of the critical path
-        # (online forward -> TD -> dgrad chain); see engine/streams.py
-        self.fj = ForkJoin(dev, 2, overlap)
-        self.overlap = self.fj.enabled
         self._graphs = None
         self.steps_done = 0
         # a timed-out poll of the direct xGMI all-reduce must not reach the parameters (engine/guard.py)
@@ -161,12 +145,6 @@ class ApexEngine(ShardedIS):
         self.T.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
 
-    def _fork(self, i: int):
-        return self.fj.fork(i)
-
-    def _join(self) -> None:
-        self.fj.join()
-
     def _forward_backward(self) -> None:
         self._fb_head()
         self._fb_torso()
@@ -176,91 +154,46 @@ class ApexEngine(ShardedIS):
         ``fc1.w`` to the end of the flat buffer (97.6 % of the parameters) is final - multi-GPU runs start its
         all-reduce here, under the conv backward that follows."""
         B, A, r, cfg = self.B, self.A, self.replay, self.cfg
-        # step_begin fused; G was zeroed by the optimizer. fused_bwd: the sampler also accumulates the max IS weight.
+        # step_begin fused; G was zeroed by the optimizer; the sampler also accumulates the max IS weight.
         # presample: from the second step on the batch was already drawn by the previous step's optimizer launch.
         if not (self.presample and self._primed):
-            r.sample(self.st, begin=True, is_n_scale=1.0 if self.fused_bwd else 0.0, n_is=self.n_is)
+            r.sample(self.st, begin=True, is_n_scale=1.0, n_is=self.n_is)
         prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None
-        if self.dual_fwd:
-            torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
-                               shared_tail=self.conv1_pair, prep=prep)
-        else:
-            if prep is not None:
-                H.conv_halo_wprep(*prep)
-            with self._fork(0):                                    # target net on s' || online net on [s ; s']
-                torso_forward(r.frames, r.frame_off[B:], B, self.Tb, self.T, self.tg)
-            torso_forward(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on)
-            self._join()
+        torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
+                           prep=prep)
         G, Pb, on = self.G, self.Pb, self.on
-        if not self.fused_bwd:
-            H.apex_td(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                      cfg.prio_eps, self.dq, self.new_prio)
-        h, a3, a2, a1 = on.h[:B], on.act3[:B], on.act2[:B], on.act1[:B]
-        sp = self.wgrad_splits
-        hb = (self.dq, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh, G.view("adv2.w"), G.view("adv2.b"),
-              G.view("val2.w"), G.view("val2.b"))
-        if self.fused_bwd:
-            # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)
-            H.apex_td_dh(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                         cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh)
-            # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
-            H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
-                     head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))
-            return
-        with self._fork(1):                                        # head dW, db: off the critical path
-            H.head_bwd(*hb, parts=2)
-        H.head_bwd(*hb, parts=1)                                   # dh
-        with self._fork(0):                                        # fc1 dW, db || fc1 dX
-            H.gemm(H.TN, self.dh, a3, G.view("fc1.w"), 1024, 3136, B, flags=H.EPI_OUT_F32, big=False)
-            H.colsum(self.dh, G.view("fc1.b"), B, 1024)
-        H.gemm(H.NN, self.dh, Pb.view("fc1.w"), self.d3.view(B, 3136), B, 3136, 1024, mask=a3, flags=H.EPI_MASK, big=False)
+        h, a3 = on.h[:B], on.act3[:B]
+        # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)
+        H.apex_td_dh(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
+                     cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh)
+        # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
+        H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
+                 head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))
 
     def _fb_torso(self) -> None:
-        """Backward of conv3 -> conv1 (weight gradients on side streams); joins every side stream at the end."""
+        """Backward of conv3 -> conv1: dX + dW + db of a layer are bodies of ONE launch (k_multi, gemm.hip). The forked
+        side-stream form it replaced (0.318 -> 0.280 ms per step) and the dCol GEMM + col2im form of the input gradient
+        (conv3 24.4 -> 15.8 us, conv2 39.3 -> 20.0 us as an implicit GEMM) are gone."""
         B, r = self.B, self.replay
         G, Pb, on = self.G, self.Pb, self.on
         a2, a1 = on.act2[:B], on.act1[:B]
         sp = self.wgrad_splits
-        if self.fused_bwd:                                         # dX + dW + db of a layer = one launch
-            # the PER priority write-back (needs only the TD kernel's output) rides along as an extra body: leaves +
-            # level 1 inside the conv3 launch, upper levels + step_end inside the conv2 launch
-            halo = self.halo_bwd                                   # dX in the LDS-halo kernel, dW + db (+ extra) in k_multi
-            if halo:
-                H.conv_halo_dgrad(3, self.d3, self.wt3, a2, self.d2, B)
-            H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else self.d2,
-                       B, splits=sp, extra=r.update_stage(1, self.new_prio))
-            if halo:
-                H.conv_halo_dgrad(2, self.d2, self.wt2, a1, self.d1, B)
-            H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else self.d1,
-                       B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st))
-            # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
-            # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
-            # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
-            H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
-                       splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None)
-            self._join()
-            return
-        with self._fork(1):                                        # conv3 dW, db || conv3 dX
-            H.conv_wgrad(3, a2, self.d3, G.view("conv3.w"), B, splits=sp)
-            H.colsum(self.d3, G.view("conv3.b"), B * 49, 64)
-        self._dgrad(3, self.d3, Pb.view("conv3.w"), self.dcol3, a2, self.d2, B)
-        with self._fork(0):                                        # conv2 dW, db || conv2 dX
-            H.conv_wgrad(2, a1, self.d2, G.view("conv2.w"), B, splits=sp)
-            H.colsum(self.d2, G.view("conv2.b"), B * 81, 64)
-        self._dgrad(2, self.d2, Pb.view("conv2.w"), self.dcol2, a1, self.d1, B)
-        with self._fork(1):
-            H.colsum(self.d1, G.view("conv1.b"), B * 400, 32)
-        H.conv_wgrad(1, r.frames, self.d1, G.view("conv1.w"), B, frame_off=r.frame_off, splits=4 * sp)
-        self._join()
-
-    @staticmethod
-    def _dgrad(layer, dy, w, dcol, act_in, dx, n) -> None:
-        """d(pre-activation) of the previous layer: implicit one-launch dgrad, or dCol GEMM + col2im gather."""
-        if H.CONV_DGRAD_IMPLICIT:
-            H.conv_dgrad(layer, dy, w, act_in, dx, n)
-        else:
-            H.conv_dcol(layer, dy, w, dcol, n)
-            H.col2im(layer, dcol, act_in, dx, n)
+        # the PER priority write-back (needs only the TD kernel's output) rides along as an extra body: leaves + level 1
+        # inside the conv3 launch, upper levels + step_end inside the conv2 launch
+        halo = self.halo_bwd                                   # dX in the LDS-halo kernel, dW + db (+ extra) in k_multi
+        if halo:
+            H.conv_halo_dgrad(3, self.d3, self.wt3, a2, self.d2, B)
+        H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else self.d2,
+                   B, splits=sp, extra=r.update_stage(1, self.new_prio))
+        if halo:
+            H.conv_halo_dgrad(2, self.d2, self.wt2, a1, self.d1, B)
+        H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else self.d1,
+                   B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st))
+        # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
+        # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
+        # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
+        H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
+                   splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None)
 
     def _optimize(self) -> None:
         cfg = self.cfg
@@ -270,8 +203,6 @@ class ApexEngine(ShardedIS):
                        copies=self.replay.handover_extra() if self.presample else None, fault=self.guard.fault)
         self.guard.mirror()
         self._primed = self.presample
-        if not self.fused_bwd:                                      # fused: done inside the conv backward launches
-            self.replay.update(self.new_prio, end_state=self.st)    # step_end fused into the tree rebuild
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
@@ -283,15 +214,11 @@ class ApexEngine(ShardedIS):
     # ---- step ---------------------------------------------------------------------------------------
     def _eager_step(self) -> None:
         if self._dist_on() and self.overlap_comm:
-            self._overlapped_step(self._fb_head_joined, self._fb_torso, self._optimize)
+            self._overlapped_step(self._fb_head, self._fb_torso, self._optimize)
             return
         self._forward_backward()
         self._all_reduce()
         self._optimize()
-
-    def _fb_head_joined(self) -> None:
-        self._fb_head()
-        self._join()
 
     def _overlapped_step(self, head, torso, optimize) -> None:
         """Data-parallel step with the gradient all-reduce hidden under the backward pass: the FC1/head slice of the
@@ -334,7 +261,7 @@ class ApexEngine(ShardedIS):
             # (the big one overlaps the conv-backward graph)
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with capture_graph(g1):
-                self._fb_head_joined()
+                self._fb_head()
             with capture_graph(g2):
                 self._fb_torso()
             with capture_graph(g3):

@@ -49,7 +49,6 @@ class SeqNetBuffers:
         self.gates = torch.zeros(T, B, 4 * Hd, **bf) if save_gates else None
         self.h2 = torch.zeros(N, 1024, **bf)
         self.q = torch.zeros(N, n_action, device=device)
-        self.sync = torch.zeros(4, dtype=torch.int32, device=device)   # persistent-recurrence arrival counters
         self.err = torch.zeros(4, dtype=torch.int32, device=device)    # ... and its timeout flag
         self.hx = H.lstm_hx(device)                                     # exchange buffer of the persistent recurrence
 
@@ -57,7 +56,7 @@ class SeqNetBuffers:
 def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
     """The library GEMM has no bias epilogue; instead of a second pass over xg (n x 4H fp32) the exchange-form recurrence
     adds b_ih + b_hh on the fly. True when both ends agree on that (same n in seq_torso_forward and seq_recurrence)."""
-    return persistent and H.LSTM_XCHG and H.use_lib_gemm(n, 4 * Hd, 3136)
+    return persistent and H.use_lib_gemm(n, 4 * Hd, 3136)
 
 
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
@@ -135,13 +134,10 @@ def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, p
     w_hh = wb.view("lstm.w_hh")
     if persistent:
         gates = buf.gates[t0:t1] if buf.gates is not None else None
-        if H.LSTM_XCHG:
-            bias = bsum if defer_xg_bias((t1 - t0) * B, Hd, persistent) else None
-            assert bias is not None or not defer_xg_bias((t1 - t0) * B, Hd, persistent), "seq_recurrence needs bsum"
-            H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx, bias)], t1 - t0, B, Hd,
-                             buf.err)
-        else:
-            H.lstm_seq_fwd([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates)], t1 - t0, B, Hd, buf.sync, buf.err)
+        bias = bsum if defer_xg_bias((t1 - t0) * B, Hd, persistent) else None
+        assert bias is not None or not defer_xg_bias((t1 - t0) * B, Hd, persistent), "seq_recurrence needs bsum"
+        H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx, bias)], t1 - t0, B, Hd,
+                         buf.err)
     else:
         for t in range(t0, t1):
             H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
@@ -217,9 +213,7 @@ class R2D2Engine(ShardedIS):
         self.dh_rec3 = torch.zeros(3, B, Hd, device=dev)     # fused BPTT step: read / accumulate / being-zeroed rotation
         self.dc2 = torch.zeros(2, B, Hd, device=dev)
         self.d3 = torch.zeros(NB * 49, 64, **bf)
-        self.dcol3 = torch.zeros(NB * 49, 576, **bf)
         self.d2 = torch.zeros(NB * 81, 64, **bf)
-        self.dcol2 = torch.zeros(NB * 81, 512, **bf)
         self.d1 = torch.zeros(NB * 400, 32, **bf)
         self.halo_bwd = H.CONV_HALO_BWD                  # conv3 / conv2 input gradients through the LDS-halo kernel
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
@@ -227,10 +221,9 @@ class R2D2Engine(ShardedIS):
         self.wgrad_splits = wgrad_splits
         _os = os
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
-        self.fused_bwd = _os.environ.get("DRL_FUSED_BWD", "1") != "0"
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
-        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1" if H.LSTM_XCHG else "0") != "0"
+        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1") != "0"
         self.dual_torso = _os.environ.get("DRL_DUAL_TORSO", "1") != "0"   # conv layers of both networks per launch (same frames)
         self.dual_heads = _os.environ.get("DRL_DUAL_HEADS", "1") != "0"   # FC + head of both networks per launch (needs dual_lstm)
         self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
@@ -333,12 +326,9 @@ class R2D2Engine(ShardedIS):
                         on_net = (self.on.xg[t0:t1], self.Pb.view("lstm.w_hh"), self.on.hs[t0:t1 + 1], self.on.cs[t0:t1 + 1],
                                   self.on.gates[t0:t1])
                         tg_net = (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1], None)
-                        if H.LSTM_XCHG:
-                            dfr = defer_xg_bias((t1 - t0) * B, Hd, True)
-                            H.lstm_seq_fwd_x([on_net + (self.on.hx, self.bsum_on if dfr else None),
-                                              tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err)
-                        else:
-                            H.lstm_seq_fwd([on_net, tg_net], t1 - t0, B, Hd, self.on.sync, self.on.err)
+                        dfr = defer_xg_bias((t1 - t0) * B, Hd, True)
+                        H.lstm_seq_fwd_x([on_net + (self.on.hx, self.bsum_on if dfr else None),
+                                          tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err)
                 else:
                     with fj.fork(2):
                         seq_recurrence(T, B, Hd, self.Tb, self.tg, pl, steps=st_, bsum=self.bsum_tg)
@@ -457,36 +447,18 @@ class R2D2Engine(ShardedIS):
             H.gemm_big(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), mask=a3)      # ReLU mask in the epilogue
         else:
             H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
-        if self.fused_bwd:                                          # dX + dW + db of a conv layer = one launch (k_multi)
-            # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
-            halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
-            if halo:
-                H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
-            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else d2, n, splits=sp,
-                       variant=4 if n >= 2048 else None)
-            if halo:
-                H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
-            H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
-            H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
-                       frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
-            return
-        H.conv_wgrad(3, a2, d3, G.view("conv3.w"), n, splits=sp)
-        H.colsum(d3, G.view("conv3.b"), n * 49, 64)
-        self._dgrad(3, d3, Pb.view("conv3.w"), self.dcol3, a2, d2, n)
-        H.conv_wgrad(2, a1, d2, G.view("conv2.w"), n, splits=sp)
-        H.colsum(d2, G.view("conv2.b"), n * 81, 64)
-        self._dgrad(2, d2, Pb.view("conv2.w"), self.dcol2, a1, d1, n)
-        H.colsum(d1, G.view("conv1.b"), n * 400, 32)
-        H.conv_wgrad(1, r.frames, d1, G.view("conv1.w"), n, frame_off=r.frame_off[r0 + lo:r0 + hi], splits=2 * sp)
-
-    @staticmethod
-    def _dgrad(layer, dy, w, dcol, act_in, dx, n) -> None:
-        """d(pre-activation) of the previous layer: implicit one-launch dgrad, or dCol GEMM + col2im gather."""
-        if H.CONV_DGRAD_IMPLICIT:
-            H.conv_dgrad(layer, dy, w, act_in, dx, n)
-        else:
-            H.conv_dcol(layer, dy, w, dcol, n)
-            H.col2im(layer, dcol, act_in, dx, n)
+        # dX + dW + db of a conv layer = one launch (k_multi); from ~1000 frames the dX body is the LDS-halo kernel
+        # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
+        halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
+        if halo:
+            H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
+        H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else d2, n, splits=sp,
+                   variant=4 if n >= 2048 else None)
+        if halo:
+            H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
+        H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
+        H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
+                   frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
 
     def _optimize(self) -> None:
         cfg = self.cfg

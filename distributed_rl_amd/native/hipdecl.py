@@ -36,20 +36,17 @@ SIGS = {
     "drl_gemm_nt_dual": [P, I, P, P, P, P, I, P, P, P, I, I, I, P],
     "drl_conv1_fwd_dual": [P, P, I, P, P, P, P, I, P, P, P, P],
     "drl_conv1_fwd_pair": [P, P, I, P, P, P, P, P, P, P],
-    "drl_conv1_fwd_apex": [P, P, I, P, I, P, P, P, P, P, P, P, P],
     # conv_direct.hip
-    "drl_conv_fwd_direct": [I, P, P, P, P, I, P, I, P],
+    "drl_conv1_fwd": [P, P, P, P, I, P, P],
     # conv_halo.hip
     "drl_conv_halo_fwd": [I, P, I, P, P, P, P, I, P, P, P, I, P, P, P, P, P],
     "drl_conv_halo_wprep": [P, P, P, P, P],
     "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
-    "drl_conv_dcol": [I, P, I, P, P, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
     "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P, P],
     "drl_fc_bwd": [P, P, P, P, P, P, I, I, I, P, P, I, P, P, P, P, I, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip
-    "drl_lstm_seq_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P],
     "drl_lstm_seq_fwd_x": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P],
     "drl_lstm_bptt": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P],
     # lstm.hip
@@ -60,7 +57,6 @@ SIGS = {
     "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P],
     "drl_add2": [P, P, P, I, P],
     # conv_bwd.hip
-    "drl_col2im": [I, P, P, P, I, P],
     "drl_colsum": [P, I, I, P, P],
     "drl_relu_mask": [P, P, P, L, P],
     # xgmi_ar.hip

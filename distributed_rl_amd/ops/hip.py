@@ -341,12 +341,6 @@ def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias:
                                   _p(a2), _p(b2), _p(c2), _p(bias2), _p(mask2), _s()), "gemm_big")
 
 
-# layers whose forward uses the barrier-free direct kernels (conv_direct.hip); the others run the LDS-tiled implicit
-# GEMM (gemm.hip). Measured on MI355X at 1024 frames: conv1 20.6 us direct vs 35.4 tiled; conv2 21.3 vs 17.0; conv3
-# 16.5 vs 13.4 -> only conv1 goes direct by default.
-CONV_FWD_DIRECT = (1,)
-
-
 # tiled conv2 / conv3 forward: 0 = register ring, 1..3 = LDS-DMA mainloop (128x64 x 3 stages / 128x64 x 4 / 64x64 x 4).
 # Measured at 1024 frames: conv2 17.5 us ring vs 19.2 / 25.3 / 19.1; conv3 14.3 us ring vs 12.3 / 17.9 / 13.7.
 CONV_FWD_TILED_VARIANT = {2: 0, 3: 1}
@@ -406,19 +400,22 @@ def conv_halo_dgrad(layer: int, dy: torch.Tensor, wt: torch.Tensor, act_in: torc
 
 
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
-             frame_off: Optional[torch.Tensor] = None, relu: bool = True, direct: Optional[bool] = None,
-             variant: int = 0, prep=None) -> None:
+             frame_off: Optional[torch.Tensor] = None, relu: bool = True, tiled: Optional[int] = None, prep=None) -> None:
+    """One conv layer (+bias, +ReLU). Default kernels: conv1 = the barrier-free direct kernel (conv_direct.hip: 20.6 us at
+    1024 frames against 35.4 us tiled), conv2 / conv3 = the LDS-halo kernels (conv_halo.hip). ``tiled`` = variant of the
+    LDS-tiled implicit GEMM of gemm.hip instead (0 = register ring, 1..3 = LDS-DMA mainloops): the A/B baseline, and the
+    only form without ReLU."""
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(out, torch.bfloat16, "out")
     _chk(x, torch.uint8 if layer == 1 else torch.bfloat16, "x")
-    if layer != 1 and CONV_HALO and relu and direct is None:
+    if layer != 1 and CONV_HALO and relu and tiled is None:
         conv_halo_fwd(layer, x, frames, w, bias, out, prep=prep)
         return
     assert prep is None
-    if ((layer in CONV_FWD_DIRECT) if direct is None else direct) and relu:
-        _ck(native.hip().drl_conv_fwd_direct(layer, _p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), variant, _s()),
-            "conv_fwd_direct")
+    if layer == 1 and relu and tiled is None:
+        _ck(native.hip().drl_conv1_fwd(_p(x), _p(w), _p(bias), _p(out), frames, _p(frame_off), _s()), "conv1_fwd")
         return
-    tiled = CONV_FWD_TILED_VARIANT.get(layer, 0) if direct is None else variant
+    if tiled is None:
+        tiled = CONV_FWD_TILED_VARIANT.get(layer, 0)
     _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out),
                                   (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
 
@@ -455,19 +452,6 @@ def conv1_fwd_pair(x, frame_off, frames: int, w1, b1, out1, w2, b2, out2) -> Non
         "conv1_fwd_pair")
 
 
-def conv1_fwd_apex(x, off1, f1: int, off2, f2: int, w1, b1, out1a, out1b, w2, b2, out2) -> None:
-    """conv1 of the Ape-X learner's forward in one launch: network 1 on f1 frames (off1 -> out1a) and on f2 frames (off2 ->
-    out1b), network 2 on the same f2 frames (-> out2) - those are read and converted once for both networks."""
-    _chk(x, torch.uint8, "x"); _chk(off1, torch.int64, "off1"); _chk(off2, torch.int64, "off2")
-    for w, b in ((w1, b1), (w2, b2)):
-        _chk(w, torch.bfloat16, "w"); _chk(b, torch.float32, "bias")
-    for o, f in ((out1a, f1), (out1b, f2), (out2, f2)):
-        _chk(o, torch.bfloat16, "out")
-        assert o.numel() == f * 400 * 32 and o.is_contiguous()
-    _ck(native.hip().drl_conv1_fwd_apex(_p(x), _p(off1), f1, _p(off2), f2, _p(w1), _p(b1), _p(out1a), _p(out1b), _p(w2), _p(b2),
-                                        _p(out2), _s()), "conv1_fwd_apex")
-
-
 def gemm_nt_dual(a1, w1, b1, c1, a2, w2, b2, c2, N: int, K: int, flags: int = 0) -> None:
     """c_i = epi(a_i[M_i,K] . w_i[N,K]^T + b_i) for two (a, w, b, c) sets in one launch (64x64 LDS-DMA tiles)."""
     for a, w, c in ((a1, w1, c1), (a2, w2, c2)):
@@ -494,20 +478,12 @@ def conv_wgrad(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, 
     _ck(native.hip().drl_conv_wgrad(layer, _p(x), _p(frame_off), frames, _p(dy), _p(dw), splits, _s()), "conv_wgrad")
 
 
-def conv_dcol(layer: int, dy: torch.Tensor, w: torch.Tensor, dcol: torch.Tensor, frames: int) -> None:
-    _chk(dy, torch.bfloat16, "dy"); _chk(w, torch.bfloat16, "w"); _chk(dcol, torch.bfloat16, "dcol")
-    _ck(native.hip().drl_conv_dcol(layer, _p(dy), frames, _p(w), _p(dcol), _s()), "conv_dcol")
-
-
 def conv_dgrad(layer: int, dy: torch.Tensor, w: torch.Tensor, act_in: Optional[torch.Tensor], dx: torch.Tensor,
                frames: int) -> None:
     """Implicit input gradient of conv2 / conv3 in ONE launch (no dCol matrix, no col2im pass):
     dx = relu'(act_in) * conv_transpose(dy, w); act_in None = no mask."""
     _chk(dy, torch.bfloat16, "dy"); _chk(w, torch.bfloat16, "w"); _chk(dx, torch.bfloat16, "dx")
     _ck(native.hip().drl_conv_dgrad(layer, _p(dy), frames, _p(w), _p(act_in), _p(dx), _s()), "conv_dgrad")
-
-
-CONV_DGRAD_IMPLICIT = True     # False = dCol GEMM + col2im gather (the two-pass form)
 
 
 # body configuration of the fused launches (see drl_fc_bwd / drl_conv_bwd), measured at B = 512 (scripts/kbench.py --only
@@ -627,10 +603,6 @@ def fc_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, dw: torch.Tensor,
                                 FC_BWD_VARIANT if variant is None else variant, _s()), "fc_bwd")
 
 
-def col2im(layer: int, dcol: torch.Tensor, act_in: torch.Tensor, dx: torch.Tensor, frames: int) -> None:
-    _ck(native.hip().drl_col2im(layer, _p(dcol), _p(act_in), _p(dx), frames, _s()), "col2im")
-
-
 def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
     _chk(dy, torch.bfloat16, "dy"); _chk(db, torch.float32, "db")
     _ck(native.hip().drl_colsum(_p(dy), M, N, _p(db), _s()), "colsum")
@@ -694,37 +666,16 @@ def lstm_step(h_prev, w_hh, xg_t, c_prev, h_out, c_out, gates_out=None) -> None:
         "lstm_step")
 
 
-def lstm_seq_fwd(nets, T: int, M: int, Hd: int, sync: torch.Tensor, err: torch.Tensor) -> None:
-    """Persistent recurrence (csrc/hip/lstm_seq.hip): ONE launch runs all T steps of 1 or 2 networks.
-    ``nets`` = list of (xg [T,M,4H] f32, w_hh [4H,H] bf16 gate-interleaved, hs [T+1,M,H] bf16, cs [T+1,M,H] f32,
-    gates [T,M,4H] bf16 or None); hs[0] / cs[0] hold the initial state. ``sync`` (2 x int32) / ``err`` (1 x int32)
-    are device scratch; ``err`` turns non-zero if an inter-workgroup wait expired (check with lstm_seq_check)."""
-    assert 1 <= len(nets) <= 2
-    _chk(sync, torch.int32, "sync"); _chk(err, torch.int32, "err")
-    args = []
-    for xg, w_hh, hs, cs, gates in nets:
-        _chk(xg, torch.float32, "xg"); _chk(w_hh, torch.bfloat16, "w_hh"); _chk(hs, torch.bfloat16, "hs"); _chk(cs, torch.float32, "cs")
-        assert xg.numel() == T * M * 4 * Hd and hs.numel() == (T + 1) * M * Hd and cs.numel() == (T + 1) * M * Hd
-        assert w_hh.shape == (4 * Hd, Hd) and (gates is None or gates.numel() == T * M * 4 * Hd)
-        args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates)]
-    if len(nets) == 1:
-        args += [None] * 5
-    _ck(native.hip().drl_lstm_seq_fwd(*args, len(nets), T, M, Hd, _p(sync), _p(err), _s()), "lstm_seq_fwd")
-
-
-# exchange-buffer form of the persistent recurrence (h travels in consumer order: 4.6 vs 5.5 us per step); 0 = plain form
-LSTM_XCHG = os.environ.get("DRL_LSTM_XCHG", "1") != "0"
-
-
 def lstm_hx(device) -> torch.Tensor:
     """Scratch of one network for :func:`lstm_seq_fwd_x`: 256 KB (two 64 KB parity slots + the arrival counter)."""
     return torch.zeros(32768, dtype=torch.int64, device=device)
 
 
 def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
-    """As :func:`lstm_seq_fwd`, but h is handed between the workgroups through an exchange buffer laid out in consumer
-    order (csrc/hip/lstm_seq.hip, coalesced exchange form). ``nets`` = list of (xg, w_hh, hs, cs, gates | None, hx) or
-    (xg, w_hh, hs, cs, gates | None, hx, bias) with hx from :func:`lstm_hx` (one per network, not shared between launches
+    """Persistent recurrence (csrc/hip/lstm_seq.hip): ONE launch runs all T steps of 1 or 2 networks; h is handed between
+    the workgroups through an exchange buffer laid out in consumer order. ``nets`` = list of (xg [T,M,4H] f32, w_hh [4H,H]
+    bf16 gate-interleaved, hs [T+1,M,H] bf16, cs [T+1,M,H] f32, gates [T,M,4H] bf16 | None, hx) or (..., hx, bias);
+    hs[0] / cs[0] hold the initial state; ``err`` (1 x int32) turns non-zero if an inter-workgroup wait expired. hx from :func:`lstm_hx` (one per network, not shared between launches
     that may run at the same time); ``bias`` ([4H] fp32, gate-interleaved like xg's columns) is added to xg on the fly."""
     assert 1 <= len(nets) <= 2
     _chk(err, torch.int32, "err")

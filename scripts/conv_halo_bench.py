@@ -56,7 +56,7 @@ def main():
                                                      H._p(b2), H._p(o2), H._s())
             else:
                 def tiled():
-                    H.conv_fwd(layer, x1, w1, b1, o1, f1, direct=False, variant=H.CONV_FWD_TILED_VARIANT[layer])
+                    H.conv_fwd(layer, x1, w1, b1, o1, f1, tiled=H.CONV_FWD_TILED_VARIANT[layer])
             fns["tiled"] = tiled
             t = timeit(fns)
             flop = 2.0 * (f1 + f2) * oshape[0] * oshape[1] * 64 * K

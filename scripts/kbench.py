@@ -81,15 +81,13 @@ def main():
     H.conv_fwd(1, x, w1, b1, a1, F)
     H.conv_fwd(2, a1, w2, b2, a2, F)
     H.conv_fwd(3, a2, w3, b3, a3, F)
-    for d in (-1, 0, 1, 2, 3):
-        sfx = "_direct%d" % d if d >= 0 else "_tiled"
-        if d <= 0:
-            cases["conv1_fwd" + sfx] = (lambda d=d: H.conv_fwd(1, x, w1, b1, a1, F, direct=d >= 0), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
-        cases["conv2_fwd" + sfx] = (lambda d=d: H.conv_fwd(2, a1, w2, b2, a2, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
-        cases["conv3_fwd" + sfx] = (lambda d=d: H.conv_fwd(3, a2, w3, b3, a3, F, direct=d >= 0, variant=max(d, 0)), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
-    for v in (1, 2, 3):
-        cases["conv2_fwd_glds%d" % v] = (lambda v=v: H.conv_fwd(2, a1, w2, b2, a2, F, direct=False, variant=v), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
-        cases["conv3_fwd_glds%d" % v] = (lambda v=v: H.conv_fwd(3, a2, w3, b3, a3, F, direct=False, variant=v), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
+    cases["conv1_fwd_direct"] = (lambda: H.conv_fwd(1, x, w1, b1, a1, F), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
+    cases["conv1_fwd_tiled"] = (lambda: H.conv_fwd(1, x, w1, b1, a1, F, tiled=0), 2 * F * 400 * 32 * 256, F * (28224 + 25600))
+    cases["conv2_fwd_halo"] = (lambda: H.conv_fwd(2, a1, w2, b2, a2, F), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
+    cases["conv3_fwd_halo"] = (lambda: H.conv_fwd(3, a2, w3, b3, a3, F), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
+    for v in (0, 1, 2, 3):                            # LDS-tiled implicit GEMM: 0 = register ring, 1..3 = LDS-DMA mainloops
+        cases["conv2_fwd_tiled%d" % v] = (lambda v=v: H.conv_fwd(2, a1, w2, b2, a2, F, tiled=v), 2 * F * 81 * 64 * 512, F * (25600 + 10368))
+        cases["conv3_fwd_tiled%d" % v] = (lambda v=v: H.conv_fwd(3, a2, w3, b3, a3, F, tiled=v), 2 * F * 49 * 64 * 576, F * (10368 + 6272))
     for v in (0, 2, 3, 5, 6, 10, 11, 13, 14):
         cases["fc1_fwd_v%d" % v] = (lambda v=v: H.gemm(H.NT, a3, wfc, h, F, 1024, 3136, bias=bfc, flags=H.EPI_RELU, big=v), 2 * F * 1024 * 3136, 2 * (F * 3136 + 1024 * 3136 + F * 1024))
     # two networks per launch (Ape-X learner: online net on F frames + target net on F/2 frames)
@@ -130,14 +128,8 @@ def main():
     for v in (0, 1, 2):
         for sp in (64, 128, 256):
             cases["conv1_wgrad_off_v%d_s%d" % (v, sp)] = (lambda v=v, sp=sp: H.conv_wgrad(1, x, d1v, g1, B, frame_off=foff, splits=sp | (v << 16)), 2 * B * 400 * 32 * 256, B * 28224)
-    dc3 = torch.zeros(B * 49, 576, dtype=torch.bfloat16, device=DEV)
-    dc2 = torch.zeros(B * 81, 512, dtype=torch.bfloat16, device=DEV)
-    cases["conv3_dcol"] = (lambda: H.conv_dcol(3, d3v, w3, dc3, B), 2 * B * 49 * 64 * 576, 2 * B * 49 * 576)
-    cases["conv2_dcol"] = (lambda: H.conv_dcol(2, d2v, w2, dc2, B), 2 * B * 81 * 64 * 512, 2 * B * 81 * 512)
     cases["conv3_dgrad_impl"] = (lambda: H.conv_dgrad(3, d3v, w3, a2[:B], dx2, B), 2 * B * 81 * 64 * 576, 2 * B * (49 + 81) * 64)
     cases["conv2_dgrad_impl"] = (lambda: H.conv_dgrad(2, d2v, w2, a1[:B], dx1, B), 2 * B * 400 * 32 * 256, 2 * B * (81 * 64 + 400 * 32))
-    cases["col2im3"] = (lambda: H.col2im(3, dc3, a2[:B], dx2, B), 0, 2 * B * 49 * 576)
-    cases["col2im2"] = (lambda: H.col2im(2, dc2, a1[:B], dx1, B), 0, 2 * B * 81 * 512)
     db = torch.zeros(64, device=DEV)
     cases["colsum_d2"] = (lambda: H.colsum(d2v, db, B * 81, 64), 0, 2 * B * 81 * 64)
     cases["colsum_d1"] = (lambda: H.colsum(d1v, db, B * 400, 32), 0, 2 * B * 400 * 32)
@@ -191,19 +183,16 @@ def main():
     css = torch.zeros(Ts + 1, 64, 512, device=DEV)
     gts = torch.zeros(Ts, 64, 2048, dtype=torch.bfloat16, device=DEV)
     hss2, css2 = hss.clone(), css.clone()
-    sync, err = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
 
     def steps120():
         for t in range(Ts):
             H.lstm_step(hss[t], whh, xgs[t], css[t], hss[t + 1], css[t + 1], gts[t])
     cases["lstm_120_steps"] = (steps120, 2 * 64 * 2048 * 512 * Ts, 0)
-    cases["lstm_seq_1net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts)], Ts, 64, 512, sync, err), 2 * 64 * 2048 * 512 * Ts, 0)
     hx1, hx2 = H.lstm_hx(DEV), H.lstm_hx(DEV)
     cases["lstm_seq_x"] = (lambda: H.lstm_seq_fwd_x([(xgs, whh, hss, css, gts, hx1)], Ts, 64, 512, err), 2 * 64 * 2048 * 512 * Ts, 0)
     cases["lstm_seq_x_2net"] = (lambda: H.lstm_seq_fwd_x([(xgs, whh, hss, css, gts, hx1), (xgs, whh, hss2, css2, None, hx2)], Ts, 64,
                                                             512, err), 2 * 2 * 64 * 2048 * 512 * Ts, 0)
-    cases["lstm_seq_2net"] = (lambda: H.lstm_seq_fwd([(xgs, whh, hss, css, gts), (xgs, whh, hss2, css2, None)], Ts, 64, 512, sync, err),
-                              2 * 2 * 64 * 2048 * 512 * Ts, 0)
     # BPTT: 80 steps as the engine issues them - two launches per step vs the fused one-launch step
     Tb = 80
     dhs_b = bf(Tb, 64, 512, scale=0.05)

@@ -121,29 +121,6 @@ def test_apex_engine_graph_equals_eager_and_learns():
     assert sum(losses[-40:]) < sum(losses[:40]), (losses[:40], losses[-40:])
 
 
-def test_apex_engine_dual_forward_equals_two_stream_forward():
-    """DRL_DUAL_FWD: online + target network as ONE launch per layer (same tile bodies) vs the fork/join forward."""
-    _, cfg, rep, e1 = _setup(seed=2, rms_eps=1e-2)
-    _, _, rep2, e2 = _setup(seed=2, rms_eps=1e-2)
-    e1.dual_fwd, e2.dual_fwd = False, True
-    e1._forward_backward()
-    e2._forward_backward()
-    torch.cuda.synchronize()
-    assert torch.equal(e1.on.q, e2.on.q) and torch.equal(e1.tg.q, e2.tg.q)      # same bodies -> same bits
-    assert torch.equal(e1.on.act3, e2.on.act3) and torch.equal(e1.tg.h, e2.tg.h)
-    e1._optimize(); e2._optimize()
-    e2.use_graph = True
-    for _ in range(6):
-        e1.step()
-    for _ in range(4):
-        e2.step()                     # 2 eager steps inside capture + 4 replays
-    torch.cuda.synchronize()
-    assert e1.stats()["step"] == 7 and e2.stats()["step"] == 7
-    a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
-    assert torch.isfinite(b).all()
-    assert float((a - b).norm() / a.norm()) < 2e-5
-
-
 def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
     """world_size 1 over real RCCL (DRL_FORCE_DIST=1): the 3-graph step with the two asynchronous all-reduces hidden
     under the conv backward must train exactly like the single-graph step (an all-reduce over one rank is identity)."""
