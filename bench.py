@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): Ape-X learner transitions/s at batch 512 with a 2 M-transition HBM-resident
 prioritized replay, on synthetic 84x84x4 uint8 frames and random-init weights; plus (in "extra") the R2D2 learner
-(64 x (40+80)), batched GPU actor inference frames/s, the strong-scaling variant and - with ``--system`` - the
-concurrently sustained actor -> ring -> ingest -> learner rates.
+(64 x (40+80), 100 000 sequences resident), batched GPU actor inference frames/s, the strong-scaling variant and - at
+N = 1, unless ``--no-system`` - the concurrently sustained actor -> ring -> ingest -> learner rates of both algorithms.
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -14,7 +14,7 @@ child, relays rank 0's JSON line and exits with the child's status (non-zero if 
 One rank per GPU over RCCL. Weak scaling (the headline): every rank owns a replay shard of ``--replay`` transitions in
 its own HBM and trains on its own 512-sample batch; gradients are summed with ONE flat all-reduce per step (direct xGMI
 kernel inside the step graph when it verifies at start-up, RCCL otherwise - the line says which). A timed step is the
-complete learner iteration: PER sample -> frames read from the store -> 3 forwards -> fused TD -> backward ->
+complete learner iteration: PER sample -> plane windows read from the store -> 3 forwards -> fused TD -> backward ->
 all-reduce -> clip + RMSprop -> priority write-back (target sync included when due).
 """
 import argparse
