@@ -216,6 +216,9 @@ class R2D2Engine(ShardedIS):
         self.d2 = torch.zeros(NB * 81, 64, **bf)
         self.d1 = torch.zeros(NB * 400, 32, **bf)
         self.halo_bwd = H.CONV_HALO_BWD                  # conv3 / conv2 input gradients through the LDS-halo kernel
+        self.halo_wgrad = self.halo_bwd and H.CONV_HALO_WGRAD    # ... and their weight gradients (conv_wgrad_halo.hip)
+        if self.halo_wgrad:                              # both backward chunks run on one stream: one scratch per layer
+            self.ws2, self.ws3 = H.conv_wgrad_ws(2, device), H.conv_wgrad_ws(3, device)
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
@@ -450,13 +453,19 @@ class R2D2Engine(ShardedIS):
         # dX + dW + db of a conv layer = one launch (k_multi); from ~1000 frames the dX body is the LDS-halo kernel
         # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
         halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
-        if halo:
+        if self.halo_wgrad:                                     # ... or in the LDS-halo weight-gradient kernel
             H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
-        H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else d2, n, splits=sp,
-                   variant=4 if n >= 2048 else None)
-        if halo:
+            H.conv_wgrad_halo(3, a2, d3, G.view("conv3.w"), G.view("conv3.b"), n, self.ws3)
             H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
-        H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
+            H.conv_wgrad_halo(2, a1, d2, G.view("conv2.w"), G.view("conv2.b"), n, self.ws2)
+        else:
+            if halo:
+                H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
+            H.conv_bwd(3, a2, d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else d2, n, splits=sp,
+                       variant=4 if n >= 2048 else None)
+            if halo:
+                H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
+            H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
         H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
                    frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
 

@@ -399,6 +399,32 @@ def conv_halo_dgrad(layer: int, dy: torch.Tensor, wt: torch.Tensor, act_in: torc
     _ck(native.hip().drl_conv_halo_dgrad(layer, _p(dy), frames, _p(wt), _p(act_in), _p(dx), _s()), "conv_halo_dgrad")
 
 
+# conv2 / conv3 weight gradients through the LDS-halo kernel where the input gradients use theirs (A/B switch)
+CONV_HALO_WGRAD = CONV_HALO_BWD and os.environ.get("DRL_CONV_HALO_WGRAD", "1") != "0"
+
+
+def conv_wgrad_ws(layer: int, device) -> torch.Tensor:
+    """Scratch of the LDS-halo weight-gradient kernel: one row of fragment-ordered accumulators per workgroup (32 / 40 MB).
+    Launches that may run concurrently (different streams) need a buffer each."""
+    lib = native.hip()
+    lib.drl_conv_wgrad_halo_ws_floats.restype = ctypes.c_longlong
+    return torch.empty(int(lib.drl_conv_wgrad_halo_ws_floats(layer)), device=device)
+
+
+def conv_wgrad_halo(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, db: torch.Tensor, frames: int,
+                    ws: torch.Tensor, max_wgs: int = 0, dbg: int = 0) -> None:
+    """Weight + bias gradient of conv2 / conv3 through the LDS-halo kernel (conv_wgrad_halo.hip): dw [64, kh, kw, ci] fp32 and
+    db [64] fp32 are ACCUMULATED into (the optimizer leaves them zeroed). x = the layer's forward input, dy = the gradient of
+    its pre-activation output. ws = scratch (conv_wgrad_ws), max_wgs = workgroups (CUs) to use, 0 = all 256."""
+    assert layer in (2, 3)
+    nx, ny, K = ((400 * 32, 81 * 64, 512) if layer == 2 else (81 * 64, 49 * 64, 576))
+    _chk(x, torch.bfloat16, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
+    assert x.numel() >= frames * nx and dy.numel() >= frames * ny and dw.numel() == 64 * K and db.numel() == 64
+    _chk(ws, torch.float32, "ws")
+    _ck(native.hip().drl_conv_wgrad_halo(layer, _p(x), _p(dy), _p(dw), _p(db), _p(ws), frames, max_wgs, dbg, _s()),
+        "conv_wgrad_halo")
+
+
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,
              frame_off: Optional[torch.Tensor] = None, relu: bool = True, tiled: Optional[int] = None, prep=None) -> None:
     """One conv layer (+bias, +ReLU). Default kernels: conv1 = the barrier-free direct kernel (conv_direct.hip: 20.6 us at

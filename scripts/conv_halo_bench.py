@@ -32,6 +32,8 @@ def timeit(fns, rounds=7, iters=40):
 
 def main():
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    if len(sys.argv) > 2 and sys.argv[2] == "wgrad":
+        return wgrad(out)
     g = torch.Generator().manual_seed(0)
     for layer in (2, 3):
         ishape, oshape, K = SH[layer]
@@ -65,6 +67,32 @@ def main():
             if out:
                 out.write(json.dumps(row) + "\n")
     dgrad(out)
+    wgrad(out)
+
+
+def wgrad(out):
+    g = torch.Generator().manual_seed(2)
+    for layer in (2, 3):
+        ishape, oshape, K = SH[layer]
+        for f in (512, 2560, 5120):
+            dy = (torch.randn(f, *oshape, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+            act = torch.relu(torch.randn(f, *ishape, generator=g)).to(torch.bfloat16).to(DEV)
+            dw, db = torch.zeros(64, K, device=DEV), torch.zeros(64, device=DEV)
+            ws = H.conv_wgrad_ws(layer, DEV)
+            sp = max(8, 128 * f // 5120)
+            fns = {"halo": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws),
+                   "halo no-loads": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=1),
+                   "halo no-mfma": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=2),
+                   "halo no-epilogue": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=4),
+                   "halo only-epilogue": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=3),
+                   "halo 128 wgs": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, max_wgs=128),
+                   "split-K implicit gemm": lambda: H.conv_bwd(layer, act, dy, None, dw, db, None, f, splits=sp)}
+            t = timeit(fns)
+            flop = 2.0 * f * oshape[0] * oshape[1] * 64 * K
+            row = {"wgrad layer": layer, "frames": f, "us": t, "tflops": {k: round(flop / v / 1e6, 1) for k, v in t.items()}}
+            print(json.dumps(row), flush=True)
+            if out:
+                out.write(json.dumps(row) + "\n")
 
 
 def dgrad(out):

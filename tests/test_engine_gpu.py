@@ -363,25 +363,27 @@ def test_r2d2_engine_big_gemm_and_library_gemm_match_small_kernels(monkeypatch):
 
 @pytest.mark.parametrize("algo", ["apex", "r2d2"])
 def test_engines_halo_conv_paths_match_implicit_gemm_paths(monkeypatch, algo):
-    """conv2 / conv3 forward and input gradients through the LDS-halo kernels (conv_halo.hip; the weight pre-pass rides in
-    the conv2 forward launch) against the implicit-GEMM tiles of gemm.hip, forced on / off at test size: same Q values, same
-    loss, same flat gradient (both accumulate in fp32; the paths differ in summation order only)."""
+    """conv2 / conv3 forward, input gradients and (R2D2) weight gradients through the LDS-halo kernels (conv_halo.hip - the
+    weight pre-pass rides in the conv2 forward launch - and conv_wgrad_halo.hip) against the implicit-GEMM tiles of gemm.hip,
+    forced on / off at test size: same Q values, same loss, same flat gradient (both accumulate in fp32; the paths differ in
+    summation order only)."""
     from distributed_rl_amd.ops import hip as H
     outs = {}
-    for path in ("gemm", "halo_fwd", "halo"):
+    for path in ("gemm", "halo_fwd", "halo_dgrad", "halo"):
         monkeypatch.setattr(H, "CONV_HALO", path != "gemm")
-        monkeypatch.setattr(H, "CONV_HALO_BWD", path == "halo")
+        monkeypatch.setattr(H, "CONV_HALO_BWD", path in ("halo", "halo_dgrad"))
+        monkeypatch.setattr(H, "CONV_HALO_WGRAD", path == "halo")
         if algo == "apex":
             _, cfg, rep, eng = _setup(B=64)
-            eng.halo_bwd = path == "halo"                 # the engine itself turns it on from B = 1024
+            eng.halo_bwd = path in ("halo", "halo_dgrad")   # the engine itself turns it on from B = 1024
         else:
             _, cfg, rep, eng = _r2d2_setup(B=16, cap=48, seed=6)
-            assert eng.halo_bwd == (path == "halo")
+            assert eng.halo_bwd == (path in ("halo", "halo_dgrad")) and eng.halo_wgrad == (path == "halo")
         eng._forward_backward()
         torch.cuda.synchronize()
         outs[path] = (eng.on.q.clone(), eng.G.flat.clone(), eng.stats()["loss"])
     ref = outs["gemm"]
-    for path in ("halo_fwd", "halo"):
+    for path in ("halo_fwd", "halo_dgrad", "halo"):
         o = outs[path]
         torch.testing.assert_close(o[0], ref[0], rtol=2e-2, atol=2e-2)
         assert o[2] == pytest.approx(ref[2], rel=3e-2)

@@ -886,6 +886,32 @@ def test_conv1_fwd_pair_matches_single_network_launches(hip, frames):
     assert torch.equal(p1, outs[0]) and torch.equal(p2, outs[1])
 
 
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("frames", [1, 2, 3, 37, 511, 1300])
+def test_conv_wgrad_halo(hip, layer, frames):
+    """Weight + bias gradient of conv2 / conv3 through the LDS-halo kernel (transposed LDS reads of planar frame images, one
+    accumulation pass per workgroup) against fp32 autograd; both outputs accumulate on top of what is there."""
+    H = hip
+    x, xf, w, bias, (cin, cout, ks, s, hw) = _conv_setup(layer, frames, layer * 19 + frames)
+    oh = (hw - ks) // s + 1
+    g = torch.Generator().manual_seed(frames)
+    dy = bf(torch.randn(frames, oh, oh, cout, generator=g) * 0.1)
+    wf = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    bf_ = bias.clone().requires_grad_(True)
+    F.conv2d(xf.permute(0, 3, 1, 2), wf, bf_, stride=s).backward(dy.float().permute(0, 3, 1, 2))
+    ref_w = wf.grad.permute(0, 2, 3, 1).reshape(cout, -1)
+    dw = torch.full((cout, ks * ks * cin), 0.25, device=DEV)
+    db = torch.full((cout,), -0.5, device=DEV)
+    H.conv_wgrad_halo(layer, x.to(DEV), dy.to(DEV), dw, db, frames, H.conv_wgrad_ws(layer, DEV))
+    scale = float(ref_w.abs().max())
+    torch.testing.assert_close(dw.cpu() - 0.25, ref_w, rtol=2e-3, atol=2e-3 * scale)
+    torch.testing.assert_close(db.cpu() + 0.5, bf_.grad, rtol=2e-3, atol=2e-3 * float(bf_.grad.abs().max()))
+    # and against the split-K implicit GEMM it replaces
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    H.conv_bwd(layer, x.to(DEV), dy.to(DEV), None, dw2, db2, None, frames)
+    torch.testing.assert_close(dw.cpu() - 0.25, dw2.cpu(), rtol=2e-3, atol=2e-3 * scale)
+
+
 # ---- large-tile GEMM (csrc/hip/gemm_big.hip) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
