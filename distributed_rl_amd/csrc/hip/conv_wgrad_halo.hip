@@ -32,6 +32,9 @@ typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
 
 #define WG_T 512
 
+// b rounded up to 32 (mod 128)
+constexpr int wg_pad128(int b) { return b + ((32 - b % 128) + 128) % 128; }
+
 __device__ wg_u32x4 g_wg_zero;             // 16 zero bytes: the source of every staging load that has no frame behind it
 
 template <int H_, int C_, int KS_, int S_, int F_>
@@ -44,10 +47,9 @@ struct WgCfg {
     static constexpr int NOCT = OH <= 8 ? 8 : 12;                   // octets per frame, multiple of 4
     static constexpr int KSTEPS = NOCT / 4;
     // plane strides = 32 (mod 128): the four planes a staging wave writes side by side land on four different bank groups
-    static constexpr int pad128(int b) { return b + ((32 - b % 128) + 128) % 128; }
-    static constexpr int PLANE_X = pad128((HC + 2) * RP * 32);      // two spare rows: reads of empty slots stay inside
+    static constexpr int PLANE_X = wg_pad128((HC + 2) * RP * 32);      // two spare rows: reads of empty slots stay inside
     static constexpr int FRAME_X = CL * CB * PLANE_X;
-    static constexpr int PLANE_A = pad128(NOCT * 8 * 32);
+    static constexpr int PLANE_A = wg_pad128(NOCT * 8 * 32);
     static constexpr int FRAME_A = 4 * PLANE_A;                     // 64 output channels = 4 blocks
     static constexpr int BUF = F * (FRAME_X + FRAME_A);
     static constexpr int K = KS * KS * C, NT = K / 16;              // n-tiles of 16 k
@@ -91,7 +93,7 @@ __device__ __forceinline__ wg_s16x4 wg_tr_read(uint32_t addr) {
 
 template <class Cf>
 __global__ __launch_bounds__(WG_T, 2) void k_conv_wgrad_halo(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                             float* __restrict__ ws, float* __restrict__ db, int frames, int dbg) {
+                                                             float* __restrict__ ws, float* __restrict__ db, int frames) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem;
@@ -155,13 +157,13 @@ __global__ __launch_bounds__(WG_T, 2) void k_conv_wgrad_halo(const bf16_t* __res
         const long long f0 = (long long)g * Cf::F;
 #pragma unroll
         for (int i = 0; i < Cf::NXP; ++i) {
-            const bool ok = xo[i] >= 0 && g < ngroups && f0 + xf[i] < frames && !(dbg & 1);
+            const bool ok = xo[i] >= 0 && g < ngroups && f0 + xf[i] < frames;
             const wg_u32x4* src = ok ? reinterpret_cast<const wg_u32x4*>(x + (f0 * Cf::XCH + tid + i * WG_T) * 8) : &g_wg_zero;
             sx[i] = *src;
         }
 #pragma unroll
         for (int i = 0; i < Cf::NAP; ++i) {
-            const bool ok = ao[i] >= 0 && g < ngroups && f0 + af[i] < frames && !(dbg & 1);
+            const bool ok = ao[i] >= 0 && g < ngroups && f0 + af[i] < frames;
             const wg_u32x4* src = ok ? reinterpret_cast<const wg_u32x4*>(dy + (f0 * Cf::ACH + tid + i * WG_T) * 8) : &g_wg_zero;
             sa[i] = *src;
         }
@@ -234,25 +236,23 @@ __global__ __launch_bounds__(WG_T, 2) void k_conv_wgrad_halo(const bf16_t* __res
     __syncthreads();
     for (; grp < ngroups; grp += 2 * G_) {                          // two rounds per trip: the register sets stay static
         fetch(sx0, sa0, grp + 2 * G_);
-        if (!(dbg & 2)) compute(lds0);
+        compute(lds0);
         stash(buf1, sx1, sa1);                                      // buf1 was last read a round ago: everybody is past that barrier
         __syncthreads();
         fetch(sx1, sa1, grp + 3 * G_);
-        if (grp + G_ < ngroups && !(dbg & 2)) compute(lds0 + Cf::BUF);
+        if (grp + G_ < ngroups) compute(lds0 + Cf::BUF);
         stash(buf0, sx0, sa0);
         __syncthreads();
     }
 
     // ---- the workgroup's accumulators, in fragment order: 256 contiguous bytes per store instruction ----
-    if (!(dbg & 4)) {
-        float* out = ws + (long long)blockIdx.x * Cf::PART + (wave * 4 * Cf::NTW * 4) * 64 + lane;
+    float* out = ws + (long long)blockIdx.x * Cf::PART + (wave * 4 * Cf::NTW * 4) * 64 + lane;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int t = 0; t < Cf::NTW; ++t)
+        for (int t = 0; t < Cf::NTW; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[((m * Cf::NTW + t) * 4 + j) * 64] = acc[m][t][j];
-    }
+            for (int j = 0; j < 4; ++j) out[((m * Cf::NTW + t) * 4 + j) * 64] = acc[m][t][j];
     // bias gradient: thread tid summed channels 8 (tid % 8) .. + 7
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_reduce(const float* __restri
 
 #define WG_MAX_GRID 256
 template <class Cf>
-static int launch_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int frames, int max_wgs, int dbg, hipStream_t s) {
+static int launch_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int frames, int max_wgs, hipStream_t s) {
     auto kern = k_conv_wgrad_halo<Cf>;
     constexpr int LDS = 2 * Cf::BUF + WG_T * 16;
     static_assert(LDS <= 160 * 1024 && LDS >= 8 * WG_T * 4, "two frame buffers + dump; the bias reduction reuses them");
@@ -304,28 +304,257 @@ static int launch_wgrad(const void* x, const void* dy, float* dw, float* db, flo
     const int ngroups = (frames + Cf::F - 1) / Cf::F;
     if (max_wgs <= 0 || max_wgs > WG_MAX_GRID) max_wgs = WG_MAX_GRID;
     const int grid = ngroups < max_wgs ? ngroups : max_wgs;
-    kern<<<grid, WG_T, LDS, s>>>((const bf16_t*)x, (const bf16_t*)dy, ws, db, frames, dbg);
-    if (!(dbg & 4)) {
-        const int groups = grid >= 64 ? 8 : (grid >= 8 ? 2 : 1);
-        k_conv_wgrad_reduce<Cf><<<dim3(Cf::PART / 256, groups), 256, 0, s>>>(ws, dw, grid);
-    }
+    kern<<<grid, WG_T, LDS, s>>>((const bf16_t*)x, (const bf16_t*)dy, ws, db, frames);
+    const int groups = grid >= 64 ? 8 : (grid >= 8 ? 2 : 1);
+    k_conv_wgrad_reduce<Cf><<<dim3(Cf::PART / 256, groups), 256, 0, s>>>(ws, dw, grid);
     return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1: dW1[co][c][kh][kw] = 1/255 * sum dy[frame][oy][ox][co] * plane[c][4 oy + kh][4 ox + kw]  (8 x 8, stride 4, u8 planes)
+// ---------------------------------------------------------------------------------------------------------------------
+// Space-to-depth makes it the same problem as above: with kh = 4 a + r, kw = 4 b + t the 84 x 84 x 4 stack is a 21 x 21 image
+// of 64-vectors (c, r, t) - position (yy, xx) holds the 4 x 4 pixel block of each plane - and conv1 is a 2 x 2, stride-1
+// convolution over it with 64 input channels. A 16-channel block = plane c, so the LDS image is planar per plane: staging
+// converts 16 u8 pixels of a plane row (one 16-byte load) into four 8-byte pieces (4 pixels = 4 consecutive t) of four
+// neighbouring positions. The work unit is HALF a frame (output rows 10 hf .. 10 hf + 9: 11 position rows = 44 contiguous
+// plane rows = 3696 bytes per plane, 231 whole chunks), two units double-buffered in 88 KB. A 20-wide output row = two
+// full octets + 4 pixels; the leftovers of two rows share an octet: 25 octets per unit -> 7 k-steps (89 % of the slots).
+// 32 output channels = 2 m-tiles; a wave owns 2 of the 16 n-tiles ((a, b) x plane).
+struct Wg1 {
+    static constexpr int RP = 21, NOCT = 28, KSTEPS = 7, F = 1;
+    static constexpr int PLANE_X = wg_pad128(11 * RP * 32), FRAME_X = 4 * PLANE_X;
+    static constexpr int PLANE_A = wg_pad128(NOCT * 8 * 32), FRAME_A = 2 * PLANE_A;
+    static constexpr int BUF = FRAME_X + FRAME_A;
+    static constexpr int XCH = 4 * 231, ACH = 200 * 4;              // 16-byte chunks of a unit: u8 planes / dy
+    static constexpr int NXP = (XCH + WG_T - 1) / WG_T, NAP = (ACH + WG_T - 1) / WG_T;
+    static constexpr int PART = 8 * 2 * 2 * 4 * 64;                 // floats of a workgroup's accumulators
+    static constexpr int K = 256;
+};
+
+__device__ __forceinline__ int wg1_oct_pix(int o, int e) {
+    if (o >= 25) return 0;
+    const int rp = o / 5, j = o - rp * 5;
+    if (j < 4) return (2 * rp + (j >> 1)) * Wg1::RP + (j & 1) * 8 + e;
+    return e < 4 ? (2 * rp) * Wg1::RP + 16 + e : (2 * rp + 1) * Wg1::RP + 12 + e;
+}
+__device__ __forceinline__ int wg1_slot(int oyl, int ox) {
+    const int rp = oyl >> 1, par = oyl & 1;
+    return ox < 16 ? (5 * rp + 2 * par + (ox >> 3)) * 8 + (ox & 7) : (5 * rp + 4) * 8 + par * 4 + (ox - 16);
+}
+// 4 u8 -> 4 bf16 (exact): v_cvt_f32_ubyteN x 4, one v_perm_b32 per pair keeps the two high halves
+__device__ __forceinline__ uint2 wg1_u8x4_to_bf16(uint32_t v) {
+    const float f0 = (float)(v & 0xffu), f1 = (float)((v >> 8) & 0xffu), f2 = (float)((v >> 16) & 0xffu), f3 = (float)(v >> 24);
+    return make_uint2(__builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u),
+                      __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u));
+}
+
+__global__ __launch_bounds__(WG_T, 2) void k_conv1_wgrad_halo(const uint8_t* __restrict__ store, const long long* __restrict__ frame_off,
+                                                              const bf16_t* __restrict__ dy, float* __restrict__ ws,
+                                                              float* __restrict__ db, int frames) {
+    typedef Wg1 Cf;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)smem;
+    for (int i = tid; i < 2 * Cf::BUF / 16; i += WG_T) reinterpret_cast<wg_u32x4*>(smem)[i] = wg_u32x4{0, 0, 0, 0};
+
+    const int h = lane >> 5, e = ((lane >> 4) & 1) * 4 + ((lane >> 2) & 3), p = lane & 3;
+    uint32_t vA[2], vB[Cf::KSTEPS][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        vA[s] = (uint32_t)(((2 * h + s) * 8 + e) * 32 + p * 8);
+#pragma unroll
+        for (int ks = 0; ks < Cf::KSTEPS; ++ks) vB[ks][s] = (uint32_t)(wg1_oct_pix(4 * ks + 2 * h + s, e) * 32 + p * 8);
+    }
+    uint32_t woff[2];                                               // n-tile nt = 4 (2 a + b) + c
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int nt = 2 * wave + t, tap = nt >> 2, c = nt & 3;
+        woff[t] = (uint32_t)__builtin_amdgcn_readfirstlane(c * Cf::PLANE_X + ((tap >> 1) * Cf::RP + (tap & 1)) * 32);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int nunits = 2 * frames;
+    // staging plan of this thread: x chunk j = plane j / 231, 16 pixels from byte 16 (j % 231) of the unit's 44 plane rows
+    int xsrc[Cf::NXP], xdst[Cf::NXP][4], ao[Cf::NAP];
+#pragma unroll
+    for (int i = 0; i < Cf::NXP; ++i) {
+        const int j = tid + i * WG_T, c = j / 231, jj = j - c * 231;
+        xsrc[i] = j < Cf::XCH ? c * 7056 + jj * 16 : -1;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int lp = jj * 16 + 4 * g4, yl = lp / 84, xx = (lp - yl * 84) >> 2;
+            xdst[i][g4] = j < Cf::XCH ? c * Cf::PLANE_X + ((yl >> 2) * Cf::RP + xx) * 32 + (yl & 3) * 8 : -1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < Cf::NAP; ++i) {
+        const int j = tid + i * WG_T, pix = j >> 2, cc = j & 3, oyl = pix / 20, ox = pix - oyl * 20;
+        ao[i] = j < Cf::ACH ? Cf::FRAME_X + (cc >> 1) * Cf::PLANE_A + wg1_slot(oyl, ox) * 32 + (cc & 1) * 16 : -1;
+    }
+    uint8_t* const buf0 = smem;
+    uint8_t* const buf1 = smem + Cf::BUF;
+    uint8_t* const dump = smem + 2 * Cf::BUF + tid * 16;
+    typedef wg_u32x4 (&XSet)[Cf::NXP];
+    typedef wg_u32x4 (&ASet)[Cf::NAP];
+    auto fetch = [&](XSet sx, ASet sa, int u) __attribute__((always_inline)) {
+        const bool uok = u < nunits;
+        const int f = min(u, nunits - 1) >> 1, hf = u & 1;
+        const long long base = frame_off[f] + hf * 3360;            // 40 plane rows
+#pragma unroll
+        for (int i = 0; i < Cf::NXP; ++i) {
+            const wg_u32x4* src = (xsrc[i] >= 0 && uok) ? reinterpret_cast<const wg_u32x4*>(store + base + xsrc[i]) : &g_wg_zero;
+            sx[i] = *src;
+        }
+#pragma unroll
+        for (int i = 0; i < Cf::NAP; ++i) {
+            const wg_u32x4* src = (ao[i] >= 0 && uok) ? reinterpret_cast<const wg_u32x4*>(dy + ((long long)u * Cf::ACH + tid + i * WG_T) * 8)
+                                                     : &g_wg_zero;
+            sa[i] = *src;
+        }
+    };
+    auto stash = [&](uint8_t* buf, XSet sx, ASet sa) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < Cf::NXP; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<uint2*>(xdst[i][g4] >= 0 ? buf + xdst[i][g4] : dump) = wg1_u8x4_to_bf16(sx[i][g4]);
+#pragma unroll
+        for (int i = 0; i < Cf::NAP; ++i) {
+            *reinterpret_cast<wg_u32x4*>(ao[i] >= 0 ? buf + ao[i] : dump) = sa[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                           // bias gradient: this chunk holds channels 8 (tid % 4) .. + 7
+                bsum[2 * c] += __uint_as_float(sa[i][c] << 16);
+                bsum[2 * c + 1] += __uint_as_float(sa[i][c] & 0xffff0000u);
+            }
+        }
+    };
+    auto compute = [&](uint32_t cur) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(cur));                               // see k_conv_wgrad_halo
+#pragma unroll
+        for (int ks = 0; ks < Cf::KSTEPS; ++ks) {
+            bf16x8 fa[2], fb[2];
+            const uint32_t a0 = cur + Cf::FRAME_X + ks * 1024;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const wg_s16x4 lo = wg_tr_read(a0 + m * Cf::PLANE_A + vA[0]), hi = wg_tr_read(a0 + m * Cf::PLANE_A + vA[1]);
+                fa[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const wg_s16x4 lo = wg_tr_read(cur + woff[t] + vB[ks][0]), hi = wg_tr_read(cur + woff[t] + vB[ks][1]);
+                fb[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(fa[m]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(fb[t]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_mfma_bf16x8, fa[m]),
+                                                                        __builtin_bit_cast(wg_mfma_bf16x8, fb[t]), acc[m][t], 0, 0, 0);
+        }
+    };
+
+    wg_u32x4 sx0[Cf::NXP], sa0[Cf::NAP], sx1[Cf::NXP], sa1[Cf::NAP];
+    const int G_ = gridDim.x;
+    int u = blockIdx.x;
+    fetch(sx0, sa0, u);
+    fetch(sx1, sa1, u + G_);
+    __syncthreads();                                                // the zero fill is complete
+    stash(buf0, sx0, sa0);
+    __syncthreads();
+    for (; u < nunits; u += 2 * G_) {
+        fetch(sx0, sa0, u + 2 * G_);
+        compute(lds0);
+        stash(buf1, sx1, sa1);
+        __syncthreads();
+        fetch(sx1, sa1, u + 3 * G_);
+        if (u + G_ < nunits) compute(lds0 + Cf::BUF);
+        stash(buf0, sx0, sa0);
+        __syncthreads();
+    }
+
+    float* out = ws + (long long)blockIdx.x * Cf::PART + (wave * 2 * 2 * 4) * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[((m * 2 + t) * 4 + j) * 64] = acc[m][t][j];
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[c * WG_T + tid] = bsum[c];
+    __syncthreads();
+    if (tid < 32) {
+        const int blk = tid >> 3, c = tid & 7;                      // channel 8 blk + c: threads with tid % 4 == blk
+        float s = 0.f;
+        for (int k = 0; k < WG_T / 4; ++k) s += red[c * WG_T + 4 * k + blk];
+        atomicAdd(db + tid, s);
+    }
+}
+
+// slot = (((wave * 2 + m) * 2 + t) * 4 + j) * 64 + lane -> co = 16 m + 4 (lane / 16) + j; n-tile 2 wave + t = 4 (2 a + b) + c,
+// column lane % 16 = 4 r + tt -> dw[co][c][4 a + r][4 b + tt]. grid = (PART / 256, row groups).
+__global__ __launch_bounds__(256) void k_conv1_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int rows) {
+    const int slot = blockIdx.x * 256 + threadIdx.x, lane = slot & 63;
+    int q = slot >> 6;
+    const int j = q & 3; q >>= 2;
+    const int t = q & 1; q >>= 1;
+    const int m = q & 1, wave = q >> 1;
+    const int nt = 2 * wave + t, tap = nt >> 2, c = nt & 3, i = lane & 15;
+    const int r0 = (int)((long long)rows * blockIdx.y / gridDim.y), r1 = (int)((long long)rows * (blockIdx.y + 1) / gridDim.y);
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0;
+    for (; r + 2 <= r1; r += 2) {
+        s0 += ws[(long long)r * Wg1::PART + slot];
+        s1 += ws[(long long)(r + 1) * Wg1::PART + slot];
+    }
+    for (; r < r1; ++r) s0 += ws[(long long)r * Wg1::PART + slot];
+    const int co = 16 * m + 4 * (lane >> 4) + j, kh = 4 * (tap >> 1) + (i >> 2), kw = 4 * (tap & 1) + (i & 3);
+    atomicAdd(dw + co * 256 + c * 64 + kh * 8 + kw, (s0 + s1) * (1.0f / 255.0f));
 }
 
 // floats of workspace the two layers need (rows of fragment-ordered accumulators, one per workgroup)
 DRL_API long long drl_conv_wgrad_halo_ws_floats(int layer) {
     if (layer == 2) return (long long)WG_MAX_GRID * WgCfg<20, 32, 4, 2, 1>::PART;
     if (layer == 3) return (long long)WG_MAX_GRID * WgCfg<9, 64, 3, 1, 2>::PART;
+    if (layer == 1) return (long long)WG_MAX_GRID * Wg1::PART;
     return -1;
+}
+
+// conv1: store = replay plane store (u8), frame_off[frames] = byte offset of each frame's 4 consecutive 84 x 84 planes,
+// dy [frames][20][20][32] bf16 -> dw [32][4][8][8] (+=, incl. the 1/255 of the forward), db [32] (+=). ws: ..._ws_floats(1).
+DRL_API int drl_conv1_wgrad_halo(const void* store, const long long* frame_off, const void* dy, float* dw, float* db, float* ws,
+                                 int frames, int max_wgs, hipStream_t s) {
+    if (frames <= 0 || !store || !frame_off || !dy || !dw || !db || !ws) return -1;
+    constexpr int LDS = 2 * Wg1::BUF + WG_T * 16;
+    static_assert(LDS <= 160 * 1024 && LDS >= 8 * WG_T * 4 && Wg1::PART % 256 == 0, "two unit buffers + dump");
+    static bool once = ((void)hipFuncSetAttribute((const void*)k_conv1_wgrad_halo, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+    (void)once;
+    if (max_wgs <= 0 || max_wgs > WG_MAX_GRID) max_wgs = WG_MAX_GRID;
+    const int nunits = 2 * frames, grid = nunits < max_wgs ? nunits : max_wgs;
+    k_conv1_wgrad_halo<<<grid, WG_T, LDS, s>>>((const uint8_t*)store, frame_off, (const bf16_t*)dy, ws, db, frames);
+    const int groups = grid >= 64 ? 8 : (grid >= 8 ? 2 : 1);
+    k_conv1_wgrad_reduce<<<dim3(Wg1::PART / 256, groups), 256, 0, s>>>(ws, dw, grid);
+    return (int)hipGetLastError();
 }
 
 // layer 2: x [frames][20][20][32], dy [frames][9][9][64] -> dw [64][4][4][32] (+=), db [64] (+=)
 // layer 3: x [frames][9][9][64],   dy [frames][7][7][64] -> dw [64][3][3][64] (+=), db [64] (+=)        (all accumulate)
 // ws: drl_conv_wgrad_halo_ws_floats(layer) floats of scratch, overwritten. max_wgs: workgroups (= CUs) to use, 0 = 256.
 DRL_API int drl_conv_wgrad_halo(int layer, const void* x, const void* dy, float* dw, float* db, float* ws, int frames, int max_wgs,
-                                int dbg, hipStream_t s) {
+                                hipStream_t s) {
     if (frames <= 0 || !x || !dy || !dw || !db || !ws) return -1;
-    if (layer == 2) return launch_wgrad<WgCfg<20, 32, 4, 2, 1>>(x, dy, dw, db, ws, frames, max_wgs, dbg, s);
-    if (layer == 3) return launch_wgrad<WgCfg<9, 64, 3, 1, 2>>(x, dy, dw, db, ws, frames, max_wgs, dbg, s);
+    if (layer == 2) return launch_wgrad<WgCfg<20, 32, 4, 2, 1>>(x, dy, dw, db, ws, frames, max_wgs, s);
+    if (layer == 3) return launch_wgrad<WgCfg<9, 64, 3, 1, 2>>(x, dy, dw, db, ws, frames, max_wgs, s);
     return -1;
 }

@@ -218,7 +218,7 @@ class R2D2Engine(ShardedIS):
         self.halo_bwd = H.CONV_HALO_BWD                  # conv3 / conv2 input gradients through the LDS-halo kernel
         self.halo_wgrad = self.halo_bwd and H.CONV_HALO_WGRAD    # ... and their weight gradients (conv_wgrad_halo.hip)
         if self.halo_wgrad:                              # both backward chunks run on one stream: one scratch per layer
-            self.ws2, self.ws3 = H.conv_wgrad_ws(2, device), H.conv_wgrad_ws(3, device)
+            self.ws1, self.ws2, self.ws3 = (H.conv_wgrad_ws(l, device) for l in (1, 2, 3))
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
@@ -466,8 +466,11 @@ class R2D2Engine(ShardedIS):
             if halo:
                 H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
             H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
-        H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
-                   frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
+        if self.halo_wgrad:
+            H.conv1_wgrad_halo(r.frames, r.frame_off[r0 + lo:r0 + hi], d1, G.view("conv1.w"), G.view("conv1.b"), n, self.ws1)
+        else:
+            H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
+                       frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))
 
     def _optimize(self) -> None:
         cfg = self.cfg

@@ -43,7 +43,8 @@ SIGS = {
     "drl_conv_halo_wprep": [P, P, P, P, P],
     "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
     # conv_wgrad_halo.hip
-    "drl_conv_wgrad_halo": [I, P, P, P, P, P, I, I, I, P],
+    "drl_conv_wgrad_halo": [I, P, P, P, P, P, I, I, P],
+    "drl_conv1_wgrad_halo": [P, P, P, P, P, P, I, I, P],
     "drl_conv_dgrad": [I, P, I, P, P, P, P],
     "drl_conv_bwd": [I, P, P, I, P, P, P, P, P, I, P, P, P],
     "drl_fc_bwd": [P, P, P, P, P, P, I, I, I, P, P, I, P, P, P, P, I, P],

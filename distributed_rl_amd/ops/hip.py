@@ -412,7 +412,7 @@ def conv_wgrad_ws(layer: int, device) -> torch.Tensor:
 
 
 def conv_wgrad_halo(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, db: torch.Tensor, frames: int,
-                    ws: torch.Tensor, max_wgs: int = 0, dbg: int = 0) -> None:
+                    ws: torch.Tensor, max_wgs: int = 0) -> None:
     """Weight + bias gradient of conv2 / conv3 through the LDS-halo kernel (conv_wgrad_halo.hip): dw [64, kh, kw, ci] fp32 and
     db [64] fp32 are ACCUMULATED into (the optimizer leaves them zeroed). x = the layer's forward input, dy = the gradient of
     its pre-activation output. ws = scratch (conv_wgrad_ws), max_wgs = workgroups (CUs) to use, 0 = all 256."""
@@ -421,8 +421,21 @@ def conv_wgrad_halo(layer: int, x: torch.Tensor, dy: torch.Tensor, dw: torch.Ten
     _chk(x, torch.bfloat16, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
     assert x.numel() >= frames * nx and dy.numel() >= frames * ny and dw.numel() == 64 * K and db.numel() == 64
     _chk(ws, torch.float32, "ws")
-    _ck(native.hip().drl_conv_wgrad_halo(layer, _p(x), _p(dy), _p(dw), _p(db), _p(ws), frames, max_wgs, dbg, _s()),
+    _ck(native.hip().drl_conv_wgrad_halo(layer, _p(x), _p(dy), _p(dw), _p(db), _p(ws), frames, max_wgs, _s()),
         "conv_wgrad_halo")
+
+
+def conv1_wgrad_halo(store: torch.Tensor, frame_off: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, db: torch.Tensor,
+                     frames: int, ws: torch.Tensor, max_wgs: int = 0) -> None:
+    """Weight + bias gradient of conv1 over the replay's plane store (frame b = 4 consecutive 84 x 84 u8 planes from byte
+    frame_off[b]) through the LDS-halo kernel: space-to-depth turns the 8 x 8 stride-4 convolution into a 2 x 2 stride-1 one
+    over a 21 x 21 x 64 image, built in LDS while staging. dw [32, 4, 8, 8] fp32 (incl. the forward's 1 / 255) and db [32]
+    are ACCUMULATED into. ws = conv_wgrad_ws(1, device)."""
+    _chk(store, torch.uint8, "store"); _chk(frame_off, torch.int64, "frame_off"); _chk(dy, torch.bfloat16, "dy")
+    _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db"); _chk(ws, torch.float32, "ws")
+    assert frame_off.numel() >= frames and dy.numel() >= frames * 400 * 32 and dw.numel() == 32 * 256 and db.numel() == 32
+    _ck(native.hip().drl_conv1_wgrad_halo(_p(store), _p(frame_off), _p(dy), _p(dw), _p(db), _p(ws), frames, max_wgs, _s()),
+        "conv1_wgrad_halo")
 
 
 def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, frames: int,

@@ -70,7 +70,27 @@ def main():
     wgrad(out)
 
 
+def wgrad1(out):
+    g = torch.Generator().manual_seed(3)
+    for f in (512, 2048, 3072, 5120):
+        store = torch.randint(0, 256, (f + 3, 7056), dtype=torch.uint8, generator=g).to(DEV)
+        off = (torch.randperm(f, generator=g) * 7056).to(DEV)                          # overlapping windows, sampled order
+        dy = (torch.randn(f, 20, 20, 32, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        dw, db, ws = torch.zeros(32, 256, device=DEV), torch.zeros(32, device=DEV), H.conv_wgrad_ws(1, DEV)
+        sp = max(16, 2 * max(8, 128 * f // 5120), f // 10)
+        fns = {"halo": lambda: H.conv1_wgrad_halo(store, off, dy, dw, db, f, ws),
+               "halo 128 wgs": lambda: H.conv1_wgrad_halo(store, off, dy, dw, db, f, ws, max_wgs=128),
+               "split-K implicit gemm": lambda: H.conv_bwd(1, store, dy, None, dw, db, None, f, frame_off=off, splits=sp)}
+        t = timeit(fns)
+        flop = 2.0 * f * 400 * 32 * 256
+        row = {"wgrad layer": 1, "frames": f, "us": t, "tflops": {k: round(flop / v / 1e6, 1) for k, v in t.items()}}
+        print(json.dumps(row), flush=True)
+        if out:
+            out.write(json.dumps(row) + "\n")
+
+
 def wgrad(out):
+    wgrad1(out)
     g = torch.Generator().manual_seed(2)
     for layer in (2, 3):
         ishape, oshape, K = SH[layer]
@@ -81,10 +101,6 @@ def wgrad(out):
             ws = H.conv_wgrad_ws(layer, DEV)
             sp = max(8, 128 * f // 5120)
             fns = {"halo": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws),
-                   "halo no-loads": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=1),
-                   "halo no-mfma": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=2),
-                   "halo no-epilogue": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=4),
-                   "halo only-epilogue": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, dbg=3),
                    "halo 128 wgs": lambda: H.conv_wgrad_halo(layer, act, dy, dw, db, f, ws, max_wgs=128),
                    "split-K implicit gemm": lambda: H.conv_bwd(layer, act, dy, None, dw, db, None, f, splits=sp)}
             t = timeit(fns)

@@ -912,6 +912,32 @@ def test_conv_wgrad_halo(hip, layer, frames):
     torch.testing.assert_close(dw.cpu() - 0.25, dw2.cpu(), rtol=2e-3, atol=2e-3 * scale)
 
 
+@pytest.mark.parametrize("frames", [1, 2, 5, 130, 700])
+def test_conv1_wgrad_halo(hip, frames):
+    """conv1 weight + bias gradient over a plane store (overlapping windows, as consecutive observations are stored) through
+    the space-to-depth LDS-halo kernel against fp32 autograd and against the split-K implicit GEMM it replaces."""
+    H = hip
+    g = torch.Generator().manual_seed(frames)
+    nplanes = frames + 9
+    store = torch.randint(0, 256, (nplanes, 7056), dtype=torch.uint8, generator=g)
+    first = torch.randint(0, nplanes - 3, (frames,), generator=g)                      # any 4 consecutive planes
+    off = first * 7056
+    stacks = store.view(nplanes, 84, 84)[first[:, None] + torch.arange(4)[None, :]]   # [frames, 4, 84, 84] = NCHW
+    dy = bf(torch.randn(frames, 20, 20, 32, generator=g) * 0.1)
+    w = torch.zeros(32, 4, 8, 8, requires_grad=True)
+    b = torch.zeros(32, requires_grad=True)
+    F.conv2d(stacks.float() / 255, w, b, stride=4).backward(dy.float().permute(0, 3, 1, 2))
+    dw = torch.full((32, 256), 0.25, device=DEV)
+    db = torch.full((32,), -0.5, device=DEV)
+    H.conv1_wgrad_halo(store.to(DEV), off.to(DEV), dy.to(DEV), dw, db, frames, H.conv_wgrad_ws(1, DEV))
+    ref = w.grad.reshape(32, 256)
+    torch.testing.assert_close(dw.cpu() - 0.25, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(db.cpu() + 0.5, b.grad, rtol=2e-3, atol=2e-3 * float(b.grad.abs().max()))
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    H.conv_bwd(1, store.to(DEV), dy.to(DEV), None, dw2, db2, None, frames, frame_off=off.to(DEV), splits=16)
+    torch.testing.assert_close(dw.cpu() - 0.25, dw2.cpu(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+
+
 # ---- large-tile GEMM (csrc/hip/gemm_big.hip) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
