@@ -198,7 +198,10 @@ class Actor:
 
     # ---- parameters -------------------------------------------------------------------------------
     def pull_params(self) -> bool:
-        got = self.params.pull(self._version)
+        # a device engine takes the parameters as a tensor: channels that receive on the GPU (collective broadcast over
+        # RCCL) hand it over without a round trip through host memory
+        pull = getattr(self.params, "pull_tensor", None) if self.engine is not None else None
+        got = pull(self._version) if pull is not None else self.params.pull(self._version)
         if got is None:
             return False
         self._version, flat = got

@@ -95,6 +95,14 @@ class CollectiveParams(ParamChannel):
                 return None
             return self._v, self._cur.detach().cpu().numpy().copy()
 
+    def pull_tensor(self, have_version: int = 0) -> Optional[Tuple[int, torch.Tensor]]:
+        """As ``pull`` but the payload stays where the broadcast put it (the actor's GPU with the nccl backend): a private
+        copy on ``self.device``, no D2H + H2D round trip through numpy. Used by actors that run a device engine
+        (reference: ape_x/actor.py:69-76 loads the pulled state_dict into the GPU model)."""
+        with self._lock:
+            if self._v <= have_version:
+                return None
+            return self._v, self._cur.detach().clone()
 
     def version(self) -> int:
         return self._v

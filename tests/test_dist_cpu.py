@@ -72,6 +72,8 @@ def _worker(rank, world, port, out_dir):
             seen, flat = got
             assert flat.shape == (pack.flat.numel(),) and float(flat[0]) == (3.0 if seen == 1 else 7.0) and float(flat[-1]) == float(flat[0])
         assert seen == 2 and ch.pull(2) is None
+        v, t = ch.pull_tensor(1)                                  # device-side hand-over: a private tensor, no numpy copy
+        assert v == 2 and isinstance(t, torch.Tensor) and t.device == ch.device and float(t[0]) == 7.0 and ch.pull_tensor(2) is None
         ch.close()
     dist.barrier()
     dist.close()
