@@ -223,6 +223,7 @@ class R2D2Engine(ShardedIS):
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
         _os = os
+        self.big_tn = H.BIG_GEMM and NB >= 1024 and _os.environ.get("DRL_BIG_TN", "1") != "0"
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
@@ -370,9 +371,15 @@ class R2D2Engine(ShardedIS):
             H.head_bwd(*hb, parts=2)
         H.head_bwd(*hb, parts=1)
         with fj.fork(0):                                            # fc1 dW, db || the BPTT chain
-            H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+            if self.big_tn:                                         # long-K, small-N products: 128 x 128 tiles of gemm_big.hip
+                H.gemm_big(H.TN, self.dh2, hs_out, G.view("fc1.w"), tile=3)
+            else:
+                H.gemm(H.TN, self.dh2, hs_out, G.view("fc1.w"), 1024, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(self.dh2, G.view("fc1.b"), NB, 1024)
-        H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
+        if self.big_tn:
+            H.gemm_big(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), tile=3)
+        else:
+            H.gemm(H.NN, self.dh2, Pb.view("fc1.w"), self.dhs.view(NB, Hd), NB, Hd, 1024, big=False)
         # BPTT: a latency-bound chain of one small launch per step (64 workgroups) that leaves 3/4 of the chip idle.
         # Everything below the LSTM is row-wise independent (weight gradients accumulate with atomics), so the window is
         # cut into time chunks and the torso backward of a chunk runs on a side stream as soon as the chain has passed
@@ -422,7 +429,10 @@ class R2D2Engine(ShardedIS):
                     self._torso_backward(k, end_of[k])
         dG = self.dG.view(NB, 4 * Hd)
         with fj.fork(0):                                            # LSTM weight gradients: need the whole window
-            H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
+            if self.big_tn:
+                H.gemm_big(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), tile=3)
+            else:
+                H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
             G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
         if H.use_lib_gemm(4 * Hd, 3136, NB):
