@@ -38,7 +38,7 @@ struct BigEpi {
     const float* bias;          // [N] or null
     const bf16_t* mask;         // [M][ldmask] forward activation (ReLU backward: out = 0 where mask <= 0) or null
     long long ldmask;
-    int out_f32;
+    int out_f32;                // bit 0: C is fp32 (else bf16); bit 1: ReLU after the bias
     // second problem of a two-problem launch (blockIdx.z == 1: same shapes, other operands - e.g. the online and the
     // target network's input projection, which fill the 256 CUs together where each alone would not)
     void* C2;
@@ -219,13 +219,17 @@ __global__ __launch_bounds__(BIG_T) void k_gemm_big(BigOperand<BM, A_TR> A, BigO
                 const float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
+            if (ep.out_f32 & 2) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+            }
             if (ep.mask) {
                 const uint2 mk = *reinterpret_cast<const uint2*>(ep.mask + (long long)m * ep.ldmask + n);
                 const uint32_t e[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) if (e[t] == 0 || (e[t] & 0x8000u)) v[t] = 0.f;     // bf16 > 0 <=> non-zero, sign clear
             }
-            if (ep.out_f32) {
+            if (ep.out_f32 & 1) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.C) + (long long)m * ep.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ep.C) + (long long)m * ep.ldc + n) =
@@ -269,7 +273,7 @@ static int big_dispatch(int tile, const BigArgs& g, const BigEpi& ep, hipStream_
 }
 
 // mode 0 (NT): C[M][N] = A[M][K] . B[N][K]^T | 1 (NN): C = A[M][K] . B[K][N] | 2 (TN): C = A[K][M]^T . B[K][N]
-// C fp32 (out_f32) or bf16; bias [N] fp32 and mask [M][ldmask] bf16 optional. lda / ldb / K multiples of 8, N / ldc of 4.
+// C fp32 (out_f32 bit 0) or bf16, ReLU after the bias (bit 1); bias [N] fp32 and mask [M][ldmask] bf16 optional. lda / ldb / K multiples of 8, N / ldc of 4.
 // a2 != null: TWO problems of the same shape in one launch (a2, b2, C2, bias2, mask2 = operands of the second).
 DRL_API int drl_gemm_big(int mode, int tile, const void* a, long long lda, const void* b, long long ldb, int M, int N, int K,
                          void* C, long long ldc, const float* bias, const void* mask, long long ldmask, int out_f32,

@@ -339,13 +339,18 @@ class R2D2Engine(ShardedIS):
             if dual and self.dual_heads:
                 # both recurrences ended in the same launch: FC + dueling head of both networks as two launches, not four
                 with fj.fork(0):
-                    N_ = T * B
-                    H.gemm_nt_dual(self.on.hs[1:].view(N_, Hd), self.Pb.view("fc1.w"), self.P.view("fc1.b"), self.on.h2,
-                                   self.tg.hs[1:].view(N_, Hd), self.Tb.view("fc1.w"), self.Tg.view("fc1.b"), self.tg.h2,
-                                   1024, Hd, flags=H.EPI_RELU)
-                    H.head_fwd_dual(self.on.h2, self.Pb.view("adv2.w"), None, self.Pb.view("val2.w"), self.P.view("val2.b"),
-                                    self.on.q, self.tg.h2, self.Tb.view("adv2.w"), None, self.Tb.view("val2.w"),
-                                    self.Tg.view("val2.b"), self.tg.q)
+                    # only the rows the loss reads (t >= burn-in: the TD kernel looks at q[t] and q[t + n] of learning steps)
+                    lo_ = burn * B if self.big_tn else 0
+                    hs_on, hs_tg = self.on.hs[1:].view(T * B, Hd)[lo_:], self.tg.hs[1:].view(T * B, Hd)[lo_:]
+                    if self.big_tn:                                 # two problems per launch, bias + ReLU in the epilogue
+                        H.gemm_big(H.NT, hs_on, self.Pb.view("fc1.w"), self.on.h2[lo_:], bias=self.P.view("fc1.b"), relu=True,
+                                   second=(hs_tg, self.Tb.view("fc1.w"), self.tg.h2[lo_:], self.Tg.view("fc1.b"), None))
+                    else:
+                        H.gemm_nt_dual(hs_on, self.Pb.view("fc1.w"), self.P.view("fc1.b"), self.on.h2,
+                                       hs_tg, self.Tb.view("fc1.w"), self.Tg.view("fc1.b"), self.tg.h2, 1024, Hd, flags=H.EPI_RELU)
+                    H.head_fwd_dual(self.on.h2[lo_:], self.Pb.view("adv2.w"), None, self.Pb.view("val2.w"), self.P.view("val2.b"),
+                                    self.on.q[lo_:], self.tg.h2[lo_:], self.Tb.view("adv2.w"), None, self.Tb.view("val2.w"),
+                                    self.Tg.view("val2.b"), self.tg.q[lo_:])
             else:
                 with fj.fork(0):
                     seq_heads(T, B, Hd, self.Pb, self.P, self.on)

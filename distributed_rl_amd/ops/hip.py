@@ -311,10 +311,10 @@ def use_big_gemm(M: int, N: int, K: int) -> bool:
 
 
 def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None,
-             mask: Optional[torch.Tensor] = None, tile: Optional[int] = None, second=None) -> None:
+             mask: Optional[torch.Tensor] = None, tile: Optional[int] = None, second=None, relu: bool = False) -> None:
     """c = a.b^T (NT: a [M,K], b [N,K]) | a.b (NN: a [M,K], b [K,N]) | a^T.b (TN: a [K,M], b [K,N]); a, b bf16 row-major
     2-D (row stride = shape[1]); c fp32 or bf16 [M,N]; ``bias`` fp32 [N] added, ``mask`` bf16 [M,N]: c = 0 where mask <= 0
-    (ReLU backward) - both in the epilogue, no second pass. ``second`` = (a2, b2, c2, bias2, mask2): a second problem of the
+    (ReLU backward), ``relu``: c = max(c, 0) after the bias - all in the epilogue, no second pass. ``second`` = (a2, b2, c2, bias2, mask2): a second problem of the
     same shape in the same launch (two networks fill the 256 CUs together where each alone would not)."""
     _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
     assert a.dim() == 2 and b.dim() == 2 and c.dim() == 2
@@ -337,7 +337,7 @@ def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias:
         assert (bias2 is None) == (bias is None) and (mask2 is None) == (mask is None)
     t = big_tile_for(M, N, 2 if second is not None else 1) if tile is None else tile
     _ck(native.hip().drl_gemm_big(mode, t, _p(a), a.shape[1], _p(b), b.shape[1], M, N, K, _p(c), N, _p(bias), _p(mask),
-                                  N if mask is not None else 0, 1 if c.dtype == torch.float32 else 0,
+                                  N if mask is not None else 0, (1 if c.dtype == torch.float32 else 0) | (2 if relu else 0),
                                   _p(a2), _p(b2), _p(c2), _p(bias2), _p(mask2), _s()), "gemm_big")
 
 

@@ -286,7 +286,10 @@ def test_r2d2_engine_graph_runs_and_learns():
     s = eng.stats()
     assert eng._graphs[0] == "one" and s["step"] == 301
     assert all(l == l for l in losses)
-    assert sum(losses[-50:]) < 0.9 * sum(losses[1:51]), (losses[1:51], losses[-50:])
+    # medians: the loss of a step is that of ITS batch, and prioritized sampling keeps drawing the hardest of the 40 sequences
+    # (a single outlier of 3.6 among values of 0.2-0.5 flipped the comparison of sums in one run out of many)
+    med = lambda v: sorted(v)[len(v) // 2]                                          # noqa: E731
+    assert med(losses[-50:]) < 0.8 * med(losses[1:51]), (losses[1:51], losses[-50:])
 
 
 def test_r2d2_engine_persistent_lstm_matches_step_launches():
