@@ -43,6 +43,7 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 #ifndef DRL_CONV1_WAVES_PER_CU
 #define DRL_CONV1_WAVES_PER_CU 8     // wave slots the tiles are dealt to (per CU): fewer waves = fewer weight set-ups
 #endif
+static int g_conv1_waves = DRL_CONV1_WAVES_PER_CU;   // host side; drl_conv1_set_waves: tuning hook
 typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma16h(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), c, 0, 0, 0);
@@ -265,7 +266,7 @@ DRL_API int drl_conv1_fwd(const void* x, const void* w, const float* bias, void*
     if (frames <= 0) return -1;
     const int M = frames * 400;
     int grid;
-    const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
+    const int per = plan((M + 15) / 16, 256 * g_conv1_waves, 4, &grid);
     const Conv1Net n1{frame_off, (const bf16_t*)w, bias, (bf16_t*)out, M, per};
     if (frame_off) k_conv1_direct<true><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
     else k_conv1_direct<false><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n1, grid);
@@ -278,7 +279,7 @@ DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int f
                                void* out2, hipStream_t s) {
     if (frames1 <= 0 || frames2 <= 0 || !frame_off1 || !frame_off2) return -1;
     int g1, g2;
-    const int slots = 256 * DRL_CONV1_WAVES_PER_CU;
+    const int slots = 256 * g_conv1_waves;
     const int M1 = frames1 * 400, M2 = frames2 * 400;
     // split the resident wave slots in proportion to the work so both networks finish together
     const int s1 = (int)((long long)slots * M1 / (M1 + M2)), s2 = slots - s1;
@@ -296,7 +297,7 @@ DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int fr
     if (frames <= 0 || !frame_off) return -1;
     const int M = frames * 400;
     int grid;
-    const int per = plan((M + 15) / 16, 256 * DRL_CONV1_WAVES_PER_CU, 4, &grid);
+    const int per = plan((M + 15) / 16, 256 * g_conv1_waves, 4, &grid);
     const Conv1Net n1{frame_off, (const bf16_t*)w1, bias1, (bf16_t*)out1, M, per};
     const Conv1Net n3{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
     k_conv1_direct<true, 1><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n3, grid);
@@ -304,4 +305,10 @@ DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int fr
 #else
     return -1;
 #endif
+}
+
+DRL_API int drl_conv1_set_waves(int waves_per_cu) {
+    if (waves_per_cu < 1 || waves_per_cu > 32) return -1;
+    g_conv1_waves = waves_per_cu;
+    return 0;
 }

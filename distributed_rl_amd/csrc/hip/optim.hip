@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
                                                  float* __restrict__ m2, bf16_t* __restrict__ p_bf16, long long n,
                                                  const float* __restrict__ partial, int n_partial, float grad_scale,
                                                  float max_norm, float lr, float a1, float a2, float eps, StepState* st,
-                                                 int zero_grad, int n_opt, CopyExtra cp, const int* __restrict__ fault) {
+                                                 int zero_grad, int n_opt, CopyExtra cp, const int* __restrict__ fault,
+                                                 long long keep0, long long keep1) {
     __shared__ float red[32];
     // optional extra block in front of the update blocks: hands the pre-drawn batch of the next step over (copies)
     const int n_smp = (int)gridDim.x - n_opt;
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
     for (long long i = (long long)ob * blockDim.x + threadIdx.x; i < n4; i += (long long)n_opt * blockDim.x) {
         float4 pv = p4[i], gv = g4[i];
         // the split-K / bias-gradient kernels of the NEXT step accumulate with atomics: hand them a zeroed buffer from
-        // this pass (the line is in flight anyway) instead of a separate memset launch
-        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // this pass (the line is in flight anyway) instead of a separate memset launch. Elements [keep0, keep1) are
+        // OVERWRITTEN by the next step (plain GEMM outputs: fc1.w, lstm.w_ih / w_hh - 96 % / 92 % of the buffer): no store
+        if (zero_grad && !(i >= keep0 && i < keep1)) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
         if (MODE == 0) {
             float4 sv = m14[i];
@@ -167,11 +169,12 @@ DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART 
     return (int)hipGetLastError();
 }
 
-// copies (optional, host pointer to a CopyExtra): done by one extra block of this launch.
+// copies (optional, host pointer to a CopyExtra): done by one extra block of this launch. [keep0, keep1): elements of g that
+// zero_grad leaves alone (multiples of 4; the caller guarantees that the next step overwrites them).
 DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long long n, const float* partial,
                              int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
-                             int zero_grad, const void* copies, const int* fault, hipStream_t s) {
-    if (n <= 0 || (n & 3)) return -1;
+                             int zero_grad, const void* copies, const int* fault, long long keep0, long long keep1, hipStream_t s) {
+    if (n <= 0 || (n & 3) || (keep0 & 3) || (keep1 & 3)) return -1;
     CopyExtra cp;
     cp.n = 0;
     if (copies) {
@@ -181,19 +184,19 @@ DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long l
     }
     const int no = grid_for(n), ns = cp.n > 0 ? 1 : 0;
     k_opt_step<0><<<no + ns, 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
-                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp, fault);
+                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2);
     return (int)hipGetLastError();
 }
 
 DRL_API int drl_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, const float* partial,
                           int n_partial, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
-                          void* st, int zero_grad, const int* fault, hipStream_t s) {
-    if (n <= 0 || (n & 3) || !st) return -1;
+                          void* st, int zero_grad, const int* fault, long long keep0, long long keep1, hipStream_t s) {
+    if (n <= 0 || (n & 3) || !st || (keep0 & 3) || (keep1 & 3)) return -1;
     CopyExtra cp;
     cp.n = 0;
     const int no = grid_for(n);
     k_opt_step<1><<<no, 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
-                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp, fault);
+                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2);
     return (int)hipGetLastError();
 }
 

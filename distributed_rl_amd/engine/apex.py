@@ -123,6 +123,8 @@ class ApexEngine(ShardedIS):
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
+        seg = self.G.layout.segments["fc1.w"]
+        self.keep = (seg.offset, seg.offset + seg.numel) if seg.offset % 4 == 0 and seg.numel % 4 == 0 else (0, 0)
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self._init_shard(replay, dist, dev)              # self.n_is: device scalar N_global / world (engine/shard.py)
@@ -200,7 +202,8 @@ class ApexEngine(ShardedIS):
         H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
                        1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
-                       copies=self.replay.handover_extra() if self.presample else None, fault=self.guard.fault)
+                       copies=self.replay.handover_extra() if self.presample else None, fault=self.guard.fault,
+                       keep=self.keep)                       # fc1.w (96 % of the buffer) is overwritten by fc_bwd: no zero store
         self.guard.mirror()
         self._primed = self.presample
 

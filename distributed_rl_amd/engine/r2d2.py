@@ -222,6 +222,9 @@ class R2D2Engine(ShardedIS):
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
+        s0, s1 = self.G.layout.segments["lstm.w_ih"], self.G.layout.segments["lstm.w_hh"]
+        contiguous = s1.offset == s0.offset + s0.numel and s0.offset % 4 == 0 and (s0.numel + s1.numel) % 4 == 0
+        self.keep = (s0.offset, s1.offset + s1.numel) if contiguous else (0, 0)
         _os = os
         self.big_tn = H.BIG_GEMM and NB >= 1024 and _os.environ.get("DRL_BIG_TN", "1") != "0"
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
@@ -492,7 +495,7 @@ class R2D2Engine(ShardedIS):
         H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
         H.adam_step(self.P.flat, self.G.flat, self.M1.flat, self.M2.flat, self.Pb.flat, self.partial, self.n_partial,
                     1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps, self.st,
-                    zero_grad=True, fault=self.guard.fault)
+                    zero_grad=True, fault=self.guard.fault, keep=self.keep)   # lstm.w_ih / w_hh: plain GEMM outputs
         # step_end fused into the tree rebuild; a discarded step writes no priorities (they come from garbage Q values)
         self.replay.update(self.new_prio, end_state=self.st, fault=self.guard.fault)
         self.guard.mirror()

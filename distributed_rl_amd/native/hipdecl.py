@@ -21,8 +21,8 @@ SIGS = {
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
     "drl_grad_sumsq": [P, L, P, POINTER(c_int), P, P, P, P, P, P],
-    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P, P],
-    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P, P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P, L, L, P],
+    "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P, L, L, P],
     "drl_cast_bf16": [P, P, L, P],
     # head.hip
     "drl_head_fwd": [P, I, I, P, P, P, P, P, P, P, I, U, P, P],
@@ -38,6 +38,7 @@ SIGS = {
     "drl_conv1_fwd_pair": [P, P, I, P, P, P, P, P, P, P],
     # conv_direct.hip
     "drl_conv1_fwd": [P, P, P, P, I, P, P],
+    "drl_conv1_set_waves": [I],
     # conv_halo.hip
     "drl_conv_halo_fwd": [I, P, I, P, P, P, P, I, P, P, P, I, P, P, P, P, P],
     "drl_conv_halo_wprep": [P, P, P, P, P],

@@ -230,19 +230,23 @@ def lstm_set_spin_limit(n: int) -> None:
 
 
 def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st,
-                 zero_grad: bool = False, copies: Optional["CopyExtra"] = None, fault: Optional[torch.Tensor] = None) -> None:
-    """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch). ``copies``
+                 zero_grad: bool = False, copies: Optional["CopyExtra"] = None, fault: Optional[torch.Tensor] = None,
+                 keep=(0, 0)) -> None:
+    """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch) except the
+    elements ``keep`` = [a, b), which the caller knows the next step OVERWRITES (plain GEMM outputs). ``copies``
     (see copy_extra) are done by one extra block of the same launch. ``fault`` (see grad_sumsq): non-zero = the step is
     discarded (nothing but the gradient zeroing and the copies happens)."""
     _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
                                       max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0,
-                                      ctypes.byref(copies) if copies is not None else None, _p(fault), _s()), "rmsprop_step")
+                                      ctypes.byref(copies) if copies is not None else None, _p(fault), keep[0], keep[1], _s()),
+        "rmsprop_step")
 
 
 def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st,
-              zero_grad: bool = False, fault: Optional[torch.Tensor] = None) -> None:
+              zero_grad: bool = False, fault: Optional[torch.Tensor] = None, keep=(0, 0)) -> None:
     _ck(native.hip().drl_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
-                                   max_norm, lr, b1, b2, eps, _p(st), 1 if zero_grad else 0, _p(fault), _s()), "adam_step")
+                                   max_norm, lr, b1, b2, eps, _p(st), 1 if zero_grad else 0, _p(fault), keep[0], keep[1], _s()),
+        "adam_step")
 
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
@@ -457,6 +461,10 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
         tiled = CONV_FWD_TILED_VARIANT.get(layer, 0)
     _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out),
                                   (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
+
+
+if os.environ.get("DRL_CONV1_WAVES"):                 # tuning hook: wave slots per CU the conv1 tiles are dealt to (default 8)
+    native.hip().drl_conv1_set_waves(int(os.environ["DRL_CONV1_WAVES"]))
 
 
 def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None,
