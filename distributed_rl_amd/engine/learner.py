@@ -94,7 +94,7 @@ class _AsyncPublisher:
 class HipLearner:
     def __init__(self, algorithm: str, n_action: int, cfg, exp: ExperienceChannel, params: ParamChannel, metrics=None,
                  replay_size: int = 100_000, device="cuda", heartbeat=None, dist=None, use_graph: bool = True,
-                 publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0):
+                 publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0, save_replay: bool = False):
         self.algorithm, self.cfg = algorithm, cfg
         self.exp, self.params, self.metrics, self.heartbeat, self.dist = exp, params, metrics, heartbeat, dist
         self.device = torch.device(device)
@@ -116,6 +116,7 @@ class HipLearner:
             self.replay = DevicePER(replay_size, self.device, batch_size=cfg.batch_size, seed=seed, planes_per_item=ppi)
             self.engine = ApexEngine(n_action, cfg, self.replay, self.device, dist=dist, use_graph=use_graph)
         self.publish_interval = publish_interval
+        self.save_replay = save_replay          # also write model_<t>.replay.pth (the whole HBM replay: opt-in, large)
         self.max_blocks = max_blocks_per_step
         self.step = 0
         self._last_pub = 0.0
@@ -185,6 +186,10 @@ class HipLearner:
                    opt_flat=[t.flat.cpu() for t in ((e.SQ,) if not self.is_r2d2 else (e.M1, e.M2))],
                    step_state=e.st.cpu())
         torch.save(aux, path[:-4] + ".aux.pth")
+        if self.save_replay:
+            if self.pipe is not None:
+                self.pipe.flush()                                           # blocks in flight become part of the snapshot
+            torch.save(self.replay.snapshot(), path[:-4] + ".replay.pth")
         return path
 
     def resume(self, path: str) -> int:
@@ -207,6 +212,10 @@ class HipLearner:
         else:
             e.sync_target()
         e.steps_done = self.step
+        rp = path[:-4] + ".replay.pth"
+        if os.path.exists(rp):                                              # plain tensors only: nothing is executed on load
+            n = self.replay.restore(torch.load(rp, map_location="cpu", weights_only=True, mmap=True))
+            self.ingested += n
         return self.step
 
     def wait_memory(self, n: int, timeout: Optional[float] = None) -> bool:
@@ -292,7 +301,7 @@ def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
     dist = Dist(device=device) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
     seed_ = (args.seed or 0) + (dist.rank if dist is not None else 0)      # every shard samples its own stream
     learner = HipLearner(args.algorithm, n_action, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb, dist=dist,
-                         seed=seed_)
+                         seed=seed_, save_replay=getattr(args, "save_replay", False))
     if dist is not None:                                                   # identical initial weights on every rank
         dist.broadcast_flat(learner.engine.P.flat)
         from ..ops import hip as H

@@ -227,6 +227,47 @@ class DevicePER:
             return self.ingest_planes(t("planes"), t("win_s"), t("win_s2"), t("action"), t("reward"), t("done"), t("prio"))
         return self.ingest(t("state"), t("next_state"), t("action"), t("reward"), t("done"), t("prio"))
 
+    # ---- snapshot / restore (checkpoint sidecar; SURVEY 5.4: the reference saves no replay at all) ---------------------
+    def snapshot(self) -> Dict[str, torch.Tensor]:
+        """The live content in ingestion order as plain CPU tensors (loadable with ``weights_only=True``): the planes of
+        every live block, its windows RELATIVE to its own planes, actions / rewards / dones and the CURRENT priorities (tree
+        leaves). Synchronises. 2 M transitions are ~18 GB: opt-in (``learner_node.py --save-replay``)."""
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        live = [b for b in self._blocks if b.state == 1]
+        dev = self.device
+        K = torch.tensor([b.K for b in live], dtype=torch.int64)
+        M = torch.tensor([b.M for b in live], dtype=torch.int64)
+        if not live:
+            z = lambda dt: torch.zeros(0, dtype=dt)                                   # noqa: E731
+            return dict(kind=torch.tensor([3]), K=K, M=M, planes=torch.zeros(0, PLANE_BYTES, dtype=torch.uint8), win_s=z(torch.int32),
+                        win_s2=z(torch.int32), action=z(torch.int32), reward=z(torch.float32), done=z(torch.float32),
+                        prio=z(torch.float32))
+        sidx = torch.cat([torch.arange(b.slot, b.slot + b.K) for b in live]).to(dev)
+        pidx = torch.cat([torch.arange(b.plane, b.plane + b.M) for b in live]).to(dev)
+        first = torch.repeat_interleave(torch.tensor([b.plane for b in live], dtype=torch.int64), K).to(dev)
+        return dict(kind=torch.tensor([3]), K=K, M=M, planes=self.frames[pidx].cpu(),
+                    win_s=(self.win[sidx] // PLANE_BYTES - first).to(torch.int32).cpu(),
+                    win_s2=(self.win[self.capacity + sidx] // PLANE_BYTES - first).to(torch.int32).cpu(),
+                    action=self.act[sidx].cpu(), reward=self.rew[sidx].cpu(), done=self.done[sidx].cpu(),
+                    prio=self.tree[sidx].cpu())
+
+    def restore(self, snap: Dict[str, torch.Tensor], group_items: int = 4096) -> int:
+        """Re-ingest a ``snapshot`` (into an empty or a running replay: ordinary ingestion, oldest first, so a smaller
+        replay keeps the newest part). Neighbouring blocks are merged into groups of ~``group_items`` transitions."""
+        K, M = snap["K"].tolist(), snap["M"].tolist()
+        n, k0, m0, i = 0, 0, 0, 0
+        while i < len(K):
+            j, kk, mm, shift = i, 0, 0, []
+            while j < len(K) and (j == i or kk + K[j] <= group_items):
+                shift += [mm] * K[j]
+                kk, mm, j = kk + K[j], mm + M[j], j + 1
+            sh = torch.tensor(shift, dtype=torch.int32)
+            sl, pl = slice(k0, k0 + kk), slice(m0, m0 + mm)
+            n += self.ingest_planes(snap["planes"][pl], snap["win_s"][sl] + sh, snap["win_s2"][sl] + sh, snap["action"][sl],
+                                    snap["reward"][sl], snap["done"][sl], snap["prio"][sl])
+            k0, m0, i = k0 + kk, m0 + mm, j
+        return n
+
     def fill_synthetic(self, n: Optional[int] = None, n_action: int = 4, chunk: int = 65536, seed: int = 0, nstep: int = 3,
                        run: int = 64) -> None:
         """Fill with random Atari-shaped transitions generated ON DEVICE (benchmarks: no dataset, no H2D), shaped like the

@@ -154,6 +154,31 @@ class DeviceSequenceReplay:
         t = lambda k: torch.from_numpy(np.ascontiguousarray(block[k]))  # noqa: E731
         return self.ingest(t("frames"), t("action"), t("reward"), t("done"), t("length"), t("h0"), t("c0"), t("prio"))
 
+    # ---- snapshot / restore (checkpoint sidecar) ---------------------------------------------------------
+    def snapshot(self) -> Dict[str, torch.Tensor]:
+        """The live sequences, oldest first, as plain CPU tensors (``weights_only=True`` loadable): T + 3 planes each, the
+        per-step tables, stored state and CURRENT priorities (tree leaves). 100 K sequences are 87 GB: opt-in."""
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        n, S = self.count, self.capacity
+        order = (torch.arange(n) + (self.cursor - n)) % S                     # the ring in ingestion order
+        o = order.to(self.device)
+        return dict(kind=torch.tensor([2]), planes=self.frames.view(S, self.P, PLANE_BYTES)[o].cpu(), action=self.act[o].cpu(),
+                    reward=self.rew[o].cpu(), done=self.done[o].cpu(), length=self.length[o].cpu(), h0=self.h0[o].cpu(),
+                    c0=self.c0[o].cpu(), prio=self.tree[o].cpu())
+
+    def restore(self, snap: Dict[str, torch.Tensor], chunk: int = 256) -> int:
+        """Re-ingest a ``snapshot`` (ordinary ring ingestion, oldest first)."""
+        n = int(snap["length"].shape[0])
+        assert n == 0 or tuple(snap["planes"].shape[1:]) == (self.P, PLANE_BYTES), "snapshot of another sequence length"
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            k = b - a
+            s0 = self.reserve(k)
+            self.retire(s0, k)
+            self._ring_write(self.frames, snap["planes"][a:b].reshape(k * self.P, PLANE_BYTES).to(self.device), s0, per=self.P)
+            self._fill_rest(s0, k, *(snap[f][a:b].to(self.device) for f in ("action", "reward", "done", "length", "h0", "c0", "prio")))
+        return n
+
     def fill_synthetic(self, n: Optional[int] = None, n_action: int = 4, chunk: int = 512, seed: int = 0) -> None:
         n = self.capacity if n is None else n
         dev, T = self.device, self.T

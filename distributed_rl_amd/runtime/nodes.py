@@ -158,7 +158,9 @@ def learner_main(argv=None) -> int:
     parser.add_argument('-d', '--actordevice', type=str, default='', help="Actor's device (kept for compatibility).")
     parser.add_argument('-s', '--replaysize', type=int, default=100000, help="Replay memory size.")
     parser.add_argument('--save-dir', type=str, default='./models')
-    parser.add_argument('--resume', type=str, default='', help='model_<t>.pth to resume from.')
+    parser.add_argument('--resume', type=str, default='', help='model_<t>.pth to resume from (+ its .aux.pth / .replay.pth sidecars).')
+    parser.add_argument('--save-replay', action='store_true',
+                        help='HIP engine: checkpoints also snapshot the HBM replay (model_<t>.replay.pth; can be tens of GB).')
     parser.add_argument('--batch-size', type=int, default=None)
     parser.add_argument('--start-memory-size', type=int, default=None)
     parser.add_argument('--save-timing', type=int, default=None)

@@ -58,7 +58,7 @@ def test_hip_learner_apex_end_to_end(tmp_path, run_id):
     cfg = make_config("ape_x", batch_size=32, start_memory_size=64, actor_batch=16, save_timing=5, target_update=4,
                       actor_param_period=10, fit_timing=5)
     exp, par = connect("inproc", run_id, create=True)
-    learner = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=256, device="cuda", publish_interval=0.0)
+    learner = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=256, device="cuda", publish_interval=0.0, save_replay=True)
     v0 = learner.publish(wait=True)
     env = envs.make_vec("SyntheticCatch-v0", 8, seed=0)
     net = DuelingDQN(4)
@@ -74,7 +74,7 @@ def test_hip_learner_apex_end_to_end(tmp_path, run_id):
     learner.publish(wait=True)
     assert par.version() > v0
     learner.close()
-    files = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_*.pth")) if "aux" not in p)
+    files = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_*.pth")) if "aux" not in p and "replay" not in p)
     assert files == ["model_0.pth", "model_10.pth", "model_5.pth"]
     ref = DuelingDQN(4)
     ref.load_state_dict(torch.load(tmp_path / "model_10.pth", weights_only=True))      # reference-format checkpoint
@@ -84,6 +84,21 @@ def test_hip_learner_apex_end_to_end(tmp_path, run_id):
     assert l2.resume(str(tmp_path / "model_10.pth")) == 10
     torch.testing.assert_close(l2.engine.P.flat.cpu(), ref_flat(ref))
     assert float(l2.engine.SQ.flat.abs().sum()) > 0 and l2.engine.stats()["step"] >= 10
+    # ... and the replay (--save-replay): the snapshot taken at step 10, re-ingested oldest first: same observations, tables
+    # and priorities in ingestion order
+    snap = torch.load(tmp_path / "model_10.replay.pth", weights_only=True)
+    n = int(snap["K"].sum())
+    assert len(l2.replay) == n > 64 and l2.ingested == n
+    r2, o = l2.replay, torch.arange(n, device="cuda")
+    s_, s2_ = r2.gather_stacks(o)
+    pl = snap["planes"].view(-1, 84, 84).cuda()
+    first = torch.repeat_interleave(torch.cumsum(snap["M"], 0) - snap["M"], snap["K"]).cuda()
+    for got, win in ((s_, snap["win_s"]), (s2_, snap["win_s2"])):
+        want = pl[(first + win.cuda())[:, None] + torch.arange(4, device="cuda")[None, :]].permute(0, 2, 3, 1)
+        assert torch.equal(got.view(n, 84, 84, 4), want)
+    assert torch.equal(r2.act[:n].cpu(), snap["action"]) and torch.equal(r2.rew[:n].cpu(), snap["reward"])
+    torch.testing.assert_close(r2.tree[:n].cpu(), snap["prio"])
+    assert abs(r2.total_prios() - float(snap["prio"].sum())) < 1e-3 * float(snap["prio"].sum())
     # actor picks up the newer parameters
     assert actor.pull_params() and actor._version == par.version()
 
@@ -98,7 +113,7 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     cfg = make_config("r2d2", batch_size=8, start_memory_size=10, actor_batch=2, save_timing=4, target_update=3, fit_timing=2)
     cfg.burn_in, cfg.seq_len, cfg.overlap, cfg.nstep = 4, 8, 4, 2
     exp, par = connect("inproc", run_id, create=True)
-    learner = HipLearner("r2d2", 4, cfg, exp, par, None, replay_size=64, device="cuda", publish_interval=0.0)
+    learner = HipLearner("r2d2", 4, cfg, exp, par, None, replay_size=64, device="cuda", publish_interval=0.0, save_replay=True)
     learner.publish(wait=True)
     env = envs.make_vec("SyntheticCatch-v0", 4, seed=0)
     actor = Actor(1, env, DuelingLSTMDQN(4, 4, 4, 2), cfg, exp, par, None, 2, torch.device("cpu"),
@@ -112,6 +127,17 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     m = DuelingLSTMDQN(4, 8, 4, 2)
     m.load_state_dict(sd)
     assert tuple(sd["lstm.weight_hh"].shape) == (2048, 512)
+    # resume with the replay snapshot: sequences, stored states and priorities come back in ingestion order
+    snap = torch.load(tmp_path / "model_4.replay.pth", weights_only=True)
+    n = int(snap["length"].shape[0])
+    exp2, par2 = connect("inproc", run_id + "b", create=True)
+    l2 = HipLearner("r2d2", 4, cfg, exp2, par2, None, replay_size=64, device="cuda")
+    assert l2.resume(str(tmp_path / "model_4.pth")) == 4 and len(l2.replay) == n >= 10
+    r2 = l2.replay
+    assert torch.equal(r2.frames.view(64, r2.P, -1)[:n].cpu(), snap["planes"]) and torch.equal(r2.length[:n].cpu(), snap["length"])
+    torch.testing.assert_close(r2.h0[:n].cpu(), snap["h0"])
+    torch.testing.assert_close(r2.tree[:n].cpu(), snap["prio"])
+    l2.close()
 
 
 def test_r2d2_actor_engine_matches_module():
