@@ -261,6 +261,18 @@ __global__ __launch_bounds__(256, OCC) void k_conv_halo(HaloNet n1, HaloNet n2, 
     }
 }
 
+// CUs that a concurrently running PERSISTENT kernel of another stream occupies (the LSTM recurrences: one workgroup with
+// 64 KB of LDS per CU), set by the engine around the launches that overlap with it. The workgroups here are persistent with
+// a static share of the work each: one that does not fit next to the other kernel would start when the first ones END and
+// double the launch's duration, so the grid is sized to what is resident at once.
+static int g_busy_cus = 0, g_busy_lds = 0;
+DRL_API int drl_halo_set_busy(int cus, int lds_bytes) {
+    if (cus < 0 || cus > 192 || lds_bytes < 0) return -1;
+    g_busy_cus = cus;
+    g_busy_lds = lds_bytes;
+    return 0;
+}
+
 template <int SH, int SW, int CI, int PAD, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC, int MODE>
 static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s, HaloPrep prep = HaloPrep{nullptr, nullptr, nullptr, nullptr, 0}) {
     constexpr int LDS = 2 * F * FP * 16;
@@ -269,7 +281,9 @@ static int launch_halo(HaloNet n1, HaloNet n2, hipStream_t s, HaloPrep prep = Ha
     static bool once = ((void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
     (void)once;
     // persistent workgroups: OCC per CU, dealt to the two networks in proportion to their frames
-    const int slots = 256 * OCC;
+    int fit = OCC;                                     // workgroups of this kernel that fit on a busy CU
+    if (g_busy_cus) { fit = (160 * 1024 - g_busy_lds) / LDS; fit = fit < 0 ? 0 : (fit > OCC ? OCC : fit); }
+    const int slots = (256 - g_busy_cus) * OCC + g_busy_cus * fit;
     const int g1 = (n1.frames + F - 1) / F, g2 = n2.frames > 0 ? (n2.frames + F - 1) / F : 0;
     int b1, b2 = 0;
     if (g1 + g2 <= slots) { b1 = g1; b2 = g2; }

@@ -226,6 +226,7 @@ class R2D2Engine(ShardedIS):
         contiguous = s1.offset == s0.offset + s0.numel and s0.offset % 4 == 0 and (s0.numel + s1.numel) % 4 == 0
         self.keep = (s0.offset, s1.offset + s1.numel) if contiguous else (0, 0)
         _os = os
+        self.busy_aware = _os.environ.get("DRL_HALO_BUSY", "1") != "0"   # size persistent conv grids around the recurrences
         self.big_tn = H.BIG_GEMM and NB >= 1024 and _os.environ.get("DRL_BIG_TN", "1") != "0"
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
@@ -315,8 +316,10 @@ class R2D2Engine(ShardedIS):
             for st_ in self.fwd_bounds:
                 pl = self.persistent_lstm
                 if dual and self.dual_torso:
-                    seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
-                                           (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep)
+                    # from the second chunk on the torso runs next to the recurrence of the chunk before (64 workgroups)
+                    with H.halo_busy(64 if (st_[0] > 0 and self.busy_aware) else 0):
+                        seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
+                                               (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep)
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
                                       persistent=pl, prep=prep)
@@ -471,11 +474,14 @@ class R2D2Engine(ShardedIS):
         # dX + dW + db of a conv layer = one launch (k_multi); from ~1000 frames the dX body is the LDS-halo kernel
         # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
         halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
+        # every chunk but the oldest runs next to the persistent BPTT launch of the chunk after it (32 workgroups)
+        busy = 32 if (k0 > 0 and self.persistent_bptt and self.busy_aware) else 0
         if self.halo_wgrad:                                     # ... or in the LDS-halo weight-gradient kernel
-            H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
-            H.conv_wgrad_halo(3, a2, d3, G.view("conv3.w"), G.view("conv3.b"), n, self.ws3)
-            H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
-            H.conv_wgrad_halo(2, a1, d2, G.view("conv2.w"), G.view("conv2.b"), n, self.ws2)
+            with H.halo_busy(busy) as cus:
+                H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
+                H.conv_wgrad_halo(3, a2, d3, G.view("conv3.w"), G.view("conv3.b"), n, self.ws3, max_wgs=cus)
+                H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
+                H.conv_wgrad_halo(2, a1, d2, G.view("conv2.w"), G.view("conv2.b"), n, self.ws2, max_wgs=cus)
         else:
             if halo:
                 H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)
@@ -485,7 +491,8 @@ class R2D2Engine(ShardedIS):
                 H.conv_halo_dgrad(2, d2, self.wt2, a1, d1, n)
             H.conv_bwd(2, a1, d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else d1, n, splits=sp)
         if self.halo_wgrad:
-            H.conv1_wgrad_halo(r.frames, r.frame_off[r0 + lo:r0 + hi], d1, G.view("conv1.w"), G.view("conv1.b"), n, self.ws1)
+            H.conv1_wgrad_halo(r.frames, r.frame_off[r0 + lo:r0 + hi], d1, G.view("conv1.w"), G.view("conv1.b"), n, self.ws1,
+                               max_wgs=256 - busy)
         else:
             H.conv_bwd(1, r.frames, d1, None, G.view("conv1.w"), G.view("conv1.b"), None, n,
                        frame_off=r.frame_off[r0 + lo:r0 + hi], splits=max(2 * sp, n // 10))

@@ -361,6 +361,25 @@ CONV_HALO_BWD = CONV_HALO and os.environ.get("DRL_CONV_HALO_BWD", "1") != "0"
 CONV_HALO_VARIANT = {2: int(os.environ.get("DRL_CONV2_HALO_VARIANT", "-1")), 3: int(os.environ.get("DRL_CONV3_HALO_VARIANT", "1"))}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def halo_busy(cus: int, lds_bytes: int = 66 * 1024):
+    """The LDS-halo launches issued inside run next to a PERSISTENT kernel of another stream that holds ``cus`` CUs with
+    ``lds_bytes`` of LDS each (the LSTM recurrences): their persistent grids are sized to what is resident at once
+    (conv_halo.hip drl_halo_set_busy; conv_wgrad_halo takes the same through max_wgs). Host-side state, read at launch
+    (capture) time."""
+    lib = native.hip()
+    if cus > 0:
+        _ck(lib.drl_halo_set_busy(cus, lds_bytes), "halo_set_busy")
+    try:
+        yield 256 - cus
+    finally:
+        if cus > 0:
+            lib.drl_halo_set_busy(0, 0)
+
+
 def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w2=None, b2=None, out2=None,
                   variant: Optional[int] = None, prep=None) -> None:
     """conv2 / conv3 (+bias+ReLU) of one or two networks in one launch of the LDS-halo kernel. prep (layer 2 only) = (w2, w3,

@@ -9,5 +9,4 @@ run() {
   if [ -n "$2" ]; then export DRL_BWD_CUTS="$2"; else unset DRL_BWD_CUTS; fi
   timeout -k 10 120 python scripts/r2d2_bench.py --steps 40 --warmup 5 2>&1 | grep "ms/step" >> "$out" || exit 1
 }
-run "" "" && run "40,80," "" && run "48,88," "" && run "32,76," "" && run "" "40,64" && run "" "48,64" && run "" "40" && run "" "52" \
-  && run "40,80," "40,64" && run "48,88," "48,64"
+run "" "" && run "" "44" && run "" "40" && run "" "36" && run "" "32" && run "56," "" && run "60," "" && run "68," "" && run "48,88," "" && run "" ""
