@@ -9,4 +9,4 @@ run() {
   if [ -n "$2" ]; then export DRL_BWD_CUTS="$2"; else unset DRL_BWD_CUTS; fi
   timeout -k 10 120 python scripts/r2d2_bench.py --steps 40 --warmup 5 2>&1 | grep "ms/step" >> "$out" || exit 1
 }
-run "" "" && run "" "44" && run "" "40" && run "" "36" && run "" "32" && run "56," "" && run "60," "" && run "68," "" && run "48,88," "" && run "" ""
+run "" "" && run "16,64," "" && run "24,72," "" && run "16,56," "" && run "8,64," "" && run "32,64," "" && run "16,48,84," "" && run "" ""
