@@ -535,6 +535,19 @@ def test_conv_halo_fwd(hip, layer, variant, f1, f2):
         ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, stride=s)).permute(0, 2, 3, 1)
         torch.testing.assert_close(o[:f].float().cpu(), ref, rtol=2e-2, atol=2e-2)
         assert bool((o[f] == 7.0).all())
+    # beside a persistent kernel of another stream the grid shrinks to what is resident (H.halo_busy): other shares of the
+    # frames per workgroup, bit-identical outputs
+    outs = [net[4].clone() for net in nets if net is not None]
+    for busy in (32, 64):
+        for net in nets:
+            if net is not None:
+                net[4].fill_(7.0)
+        with H.halo_busy(busy):
+            if n2 is None:
+                H.conv_halo_fwd(layer, x1, f1, w1.to(DEV), b1.to(DEV), o1, variant=variant)
+            else:
+                H.conv_halo_fwd(layer, x1, f1, w1.to(DEV), b1.to(DEV), o1, n2[0], f2, n2[2].to(DEV), n2[3].to(DEV), n2[4], variant=variant)
+        assert all(torch.equal(net[4], o) for net, o in zip([n for n in nets if n is not None], outs))
 
 
 @pytest.mark.parametrize("M1,M2", [(7, 3), (128, 64), (1024, 512)])
@@ -910,6 +923,11 @@ def test_conv_wgrad_halo(hip, layer, frames):
     dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
     H.conv_bwd(layer, x.to(DEV), dy.to(DEV), None, dw2, db2, None, frames)
     torch.testing.assert_close(dw.cpu() - 0.25, dw2.cpu(), rtol=2e-3, atol=2e-3 * scale)
+    # fewer workgroups (a neighbour holds CUs: max_wgs): other shares per workgroup, same sums up to fp32 summation order
+    dw3, db3 = torch.zeros_like(dw), torch.zeros_like(db)
+    H.conv_wgrad_halo(layer, x.to(DEV), dy.to(DEV), dw3, db3, frames, H.conv_wgrad_ws(layer, DEV), max_wgs=5)
+    torch.testing.assert_close(dw3.cpu(), ref_w, rtol=2e-3, atol=2e-3 * scale)
+    torch.testing.assert_close(db3.cpu(), bf_.grad, rtol=2e-3, atol=2e-3 * float(bf_.grad.abs().max()))
 
 
 @pytest.mark.parametrize("frames", [1, 2, 5, 130, 700])
