@@ -388,7 +388,11 @@ __global__ __launch_bounds__(WG_T, 2) void k_conv1_wgrad_halo(const uint8_t* __r
         xsrc[i] = j < Cf::XCH ? c * 7056 + jj * 16 : -1;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const int lp = jj * 16 + 4 * g4, yl = lp / 84, xx = (lp - yl * 84) >> 2;
+            // store instruction g4 of a lane writes its pixel group (g4 + lane) % 4: the 8-byte pieces of one instruction
+            // then spread over the four positions (32 B apart) x four plane rows (8 B apart) = all 32 banks. With every lane
+            // on group g4 the lanes are 128 B apart - ONE bank pair, a 32-way conflict: half of the kernel's LDS cycles
+            const int gg = (g4 + lane) & 3;
+            const int lp = jj * 16 + 4 * gg, yl = lp / 84, xx = (lp - yl * 84) >> 2;
             xdst[i][g4] = j < Cf::XCH ? c * Cf::PLANE_X + ((yl >> 2) * Cf::RP + xx) * 32 + (yl & 3) * 8 : -1;
         }
     }
@@ -420,10 +424,17 @@ __global__ __launch_bounds__(WG_T, 2) void k_conv1_wgrad_halo(const uint8_t* __r
     };
     auto stash = [&](uint8_t* buf, XSet sx, ASet sa) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < Cf::NXP; ++i)
+        for (int i = 0; i < Cf::NXP; ++i) {
+            // the chunk's four dwords rotated left by lane % 4 (two conditional swaps), so that word g4 is pixel group
+            // (g4 + lane) % 4 - the order xdst is in
+            uint32_t w0 = sx[i][0], w1 = sx[i][1], w2 = sx[i][2], w3 = sx[i][3];
+            if (lane & 1) { const uint32_t t = w0; w0 = w1; w1 = w2; w2 = w3; w3 = t; }
+            if (lane & 2) { uint32_t t = w0; w0 = w2; w2 = t; t = w1; w1 = w3; w3 = t; }
+            const uint32_t wr[4] = {w0, w1, w2, w3};
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<uint2*>(xdst[i][g4] >= 0 ? buf + xdst[i][g4] : dump) = wg1_u8x4_to_bf16(sx[i][g4]);
+                *reinterpret_cast<uint2*>(xdst[i][g4] >= 0 ? buf + xdst[i][g4] : dump) = wg1_u8x4_to_bf16(wr[g4]);
+        }
 #pragma unroll
         for (int i = 0; i < Cf::NAP; ++i) {
             *reinterpret_cast<wg_u32x4*>(ao[i] >= 0 ? buf + ao[i] : dump) = sa[i];
