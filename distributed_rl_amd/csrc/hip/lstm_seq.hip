@@ -218,10 +218,14 @@ __global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int ste
     constexpr int NWG = HD / 16, NKS = 4 * HD / 32;              // 32 workgroups, 64 k-steps of 32 gate columns
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // NKS KB: W_hh[:, 16 wg .. +15] in fragment order
-    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g4 = lane >> 4;
-    int* sync = reinterpret_cast<int*>(a.bx + BX_SYNC_BYTE_OFFSET);
+    // Row groups: batch rows never mix in the recurrence, so the M/16 row blocks are dealt to gridDim.x / NWG independent
+    // groups of NWG workgroups (blockDim.x / 64 row blocks each, own flags). What bounds a step is the 4 KB per lane of dG
+    // a wave has to pull in after the wait; with one or two waves per workgroup that load is spread over 2-4x as many CUs.
+    const int grp = blockIdx.x / NWG, wg = blockIdx.x % NWG, tid = threadIdx.x, lane = tid & 63, r = lane & 15, g4 = lane >> 4;
+    const int wave = grp * (int)(blockDim.x >> 6) + (tid >> 6);      // row block [16 wave, 16 wave + 16) of the batch
+    int* sync = reinterpret_cast<int*>(a.bx + BX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * DRL_LSTM_FLAG_STRIDE);
     // fragment (ks, lane (ii, g)) element e = W_hh[ks*32 + g*8 + e][16 wg + ii]: row n of the slice is 32 contiguous bytes
-    for (int n = tid; n < 4 * HD; n += 256) {
+    for (int n = tid; n < 4 * HD; n += (int)blockDim.x) {
         const uint4* src = reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + 16 * wg);
         const uint4 lo = src[0], hi = src[1];
         const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -314,17 +318,23 @@ __global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int ste
 // Window steps k_hi, k_hi - 1, ..., k_hi - steps + 1 (k = t - burn). first: the chain starts here (dh_rec = dc = 0);
 // carry: another launch continues below k_hi - steps + 1 (dh_rec / dc are written for it). bx: 768 KB scratch, zero when
 // first used. gates / cs are the window parts of the forward buffers (cs has one more row than gates).
+// groups: 0 = the default (g_bptt_groups, capped to the row blocks there are); else it must divide M / 16.
+static int g_bptt_groups = 4;
 DRL_API int drl_lstm_bptt(const void* dhs, const void* gates, const float* cs, void* dG, const void* w_hh, float* dh_rec, float* dc,
-                          void* bx, int k_hi, int steps, int M, int H, int first, int carry, int* err, hipStream_t s) {
+                          void* bx, int k_hi, int steps, int M, int H, int first, int carry, int groups, int* err, hipStream_t s) {
     if (H != 512 || M <= 0 || M > 64 || (M & 15) || steps <= 0 || steps >= 4095 || k_hi - steps + 1 < 0) return -1;
+    const int rbs = M / 16;
+    if (groups <= 0) { groups = g_bptt_groups; while (groups > 1 && (groups > rbs || rbs % groups)) groups >>= 1; }
+    if (groups < 1 || groups > 4 || rbs % groups) return -1;
     BpttArgs a{(const bf16_t*)dhs, (const bf16_t*)gates, cs, (bf16_t*)dG, (const bf16_t*)w_hh, dh_rec, dc, (uint8_t*)bx};
     constexpr int LDS = (4 * 512 / 32) * 1024;
     auto kern = k_lstm_bptt<512>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
     (void)once;
-    kern<<<512 / 16, 256, LDS, s>>>(a, k_hi, steps, M, first, carry, err);
+    kern<<<groups * (512 / 16), 64 * (rbs / groups), LDS, s>>>(a, k_hi, steps, M, first, carry, err);
     return (int)hipGetLastError();
 }
+DRL_API int drl_lstm_set_bptt_groups(int g) { g_bptt_groups = g < 1 ? 1 : g > 4 ? 4 : g; return 0; }
 
 DRL_API int drl_lstm_set_spin_limit(int n) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spin_limit), &n, sizeof(int));

@@ -227,6 +227,11 @@ class R2D2Engine(ShardedIS):
         self.keep = (s0.offset, s1.offset + s1.numel) if contiguous else (0, 0)
         _os = os
         self.busy_aware = _os.environ.get("DRL_HALO_BUSY", "1") != "0"   # size persistent conv grids around the recurrences
+        # row groups of the persistent BPTT (32 workgroups each; lstm_seq.hip): 80 steps alone take 366 / 270 / 271 us
+        # with 1 / 2 / 4 groups
+        self.bptt_groups = max(1, min(4, int(_os.environ.get("DRL_BPTT_GROUPS", "2"))))
+        while self.bptt_groups > 1 and (self.B // 16) % self.bptt_groups:
+            self.bptt_groups //= 2
         self.big_tn = H.BIG_GEMM and NB >= 1024 and _os.environ.get("DRL_BIG_TN", "1") != "0"
         self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
         H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
@@ -413,7 +418,7 @@ class R2D2Engine(ShardedIS):
             k_hi = L - 1
             for i, k0 in enumerate(sorted(starts, reverse=True)):    # one launch per time chunk, newest chunk first
                 H.lstm_bptt(self.dhs, on.gates[burn:T], on.cs[burn:T + 1], self.dG, w_hh, self.bptt_rec, self.bptt_dc, self.bx,
-                            self.bptt_err, k_hi=k_hi, steps=k_hi - k0 + 1, first=i == 0, carry=k0 > 0)
+                            self.bptt_err, k_hi=k_hi, steps=k_hi - k0 + 1, first=i == 0, carry=k0 > 0, groups=self.bptt_groups)
                 with fj.fork(1):
                     self._torso_backward(k0, end_of[k0])
                 k_hi = k0 - 1
@@ -474,8 +479,8 @@ class R2D2Engine(ShardedIS):
         # dX + dW + db of a conv layer = one launch (k_multi); from ~1000 frames the dX body is the LDS-halo kernel
         # body variants / split counts measured at n = 5120 frames (scripts/kbench.py --frames 10240 --only bwd_fused)
         halo = self.halo_bwd                                    # dX in the LDS-halo kernel, dW + db in k_multi
-        # every chunk but the oldest runs next to the persistent BPTT launch of the chunk after it (32 workgroups)
-        busy = 32 if (k0 > 0 and self.persistent_bptt and self.busy_aware) else 0
+        # every chunk but the oldest runs next to the persistent BPTT launch of the chunk after it (32 workgroups per row group)
+        busy = 32 * self.bptt_groups if (k0 > 0 and self.persistent_bptt and self.busy_aware) else 0
         if self.halo_wgrad:                                     # ... or in the LDS-halo weight-gradient kernel
             with H.halo_busy(busy) as cus:
                 H.conv_halo_dgrad(3, d3, self.wt3, a2, d2, n)

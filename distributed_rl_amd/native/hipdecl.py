@@ -53,7 +53,8 @@ SIGS = {
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip
     "drl_lstm_seq_fwd_x": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P],
-    "drl_lstm_bptt": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P],
+    "drl_lstm_bptt": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "drl_lstm_set_bptt_groups": [I],
     # lstm.hip
     "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
     "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],

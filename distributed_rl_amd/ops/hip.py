@@ -484,6 +484,8 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
 
 if os.environ.get("DRL_CONV1_WAVES"):                 # tuning hook: wave slots per CU the conv1 tiles are dealt to (default 8)
     native.hip().drl_conv1_set_waves(int(os.environ["DRL_CONV1_WAVES"]))
+if os.environ.get("DRL_BPTT_GROUPS"):                 # tuning hook: row groups of the persistent BPTT (1, 2, 4; default 4)
+    native.hip().drl_lstm_set_bptt_groups(int(os.environ["DRL_BPTT_GROUPS"]))
 
 
 def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None,
@@ -767,11 +769,13 @@ def lstm_bx(device) -> torch.Tensor:
     return torch.zeros(98304, dtype=torch.int64, device=device)
 
 
-def lstm_bptt(dhs, gates, cs, dG, w_hh, dh_rec, dc, bx, err, k_hi: int, steps: int, first: bool, carry: bool) -> None:
+def lstm_bptt(dhs, gates, cs, dG, w_hh, dh_rec, dc, bx, err, k_hi: int, steps: int, first: bool, carry: bool,
+              groups: int = 0) -> None:
     """Persistent BPTT (csrc/hip/lstm_seq.hip k_lstm_bptt): window steps k_hi .. k_hi - steps + 1 in ONE launch.
     dhs [L,M,H] bf16 (dL/dh from the heads), gates [L,M,4H] bf16, cs [L+1,M,H] f32 (cs[k] = c before step k), dG [L,M,4H]
     bf16 out, w_hh [4H,H] bf16; dh_rec / dc [M,H] f32 carry the chain between launches (``first``: start from zero,
-    ``carry``: write them for the launch that continues)."""
+    ``carry``: write them for the launch that continues). ``groups``: independent row groups of 32 workgroups each
+    (1, 2 or 4, dividing M/16; 0 = the library default, ``DRL_BPTT_GROUPS``)."""
     L, M, Hd = dhs.shape
     _chk(dhs, torch.bfloat16, "dhs"); _chk(gates, torch.bfloat16, "gates"); _chk(cs, torch.float32, "cs"); _chk(dG, torch.bfloat16, "dG")
     _chk(w_hh, torch.bfloat16, "w_hh"); _chk(dh_rec, torch.float32, "dh_rec"); _chk(dc, torch.float32, "dc")
@@ -779,7 +783,7 @@ def lstm_bptt(dhs, gates, cs, dG, w_hh, dh_rec, dc, bx, err, k_hi: int, steps: i
     assert gates.shape == (L, M, 4 * Hd) and cs.shape == (L + 1, M, Hd) and dG.shape == (L, M, 4 * Hd) and w_hh.shape == (4 * Hd, Hd)
     assert dh_rec.shape == (M, Hd) and dc.shape == (M, Hd) and bx.numel() >= 98304 and 0 <= k_hi - steps + 1 and k_hi < L
     _ck(native.hip().drl_lstm_bptt(_p(dhs), _p(gates), _p(cs), _p(dG), _p(w_hh), _p(dh_rec), _p(dc), _p(bx), k_hi, steps, M, Hd,
-                                   int(first), int(carry), _p(err), _s()), "lstm_bptt")
+                                   int(first), int(carry), int(groups), _p(err), _s()), "lstm_bptt")
 
 
 def lstm_seq_supported(M: int, Hd: int) -> bool:

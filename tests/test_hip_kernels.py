@@ -880,6 +880,16 @@ def test_lstm_bptt_persistent_matches_step_launches(hip, M):
     torch.cuda.synchronize()
     assert int(err.item()) == 0
     torch.testing.assert_close(dG.float().cpu(), dG_ref.float().cpu(), rtol=3e-2, atol=2e-4)
+    # row groups (independent sets of 32 workgroups, M/16/groups row blocks each): the same arithmetic in the same order,
+    # whatever the split - and the scratch may see different splits from launch to launch
+    for g1, g2 in ((1, 1), (2, 4), (4, 2), (4, 1)):
+        if M // 16 % g1 or M // 16 % g2:
+            continue
+        dG2 = torch.zeros_like(dG_ref)
+        H.lstm_bptt(dhs, gates, cs, dG2, w, rec, dc, bx, err, k_hi=L - 1, steps=4, first=True, carry=True, groups=g1)
+        H.lstm_bptt(dhs, gates, cs, dG2, w, rec, dc, bx, err, k_hi=L - 5, steps=3, first=False, carry=False, groups=g2)
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0 and torch.equal(dG2, dG), (g1, g2)
 
 
 @pytest.mark.parametrize("frames", [5, 130])
