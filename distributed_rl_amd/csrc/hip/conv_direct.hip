@@ -93,7 +93,7 @@ struct Conv1Net {
 // sequence batch. (A form for the Ape-X learner - online on s, online AND target on s' - measured no better than the
 // two-network launch below and is gone.)
 template <bool OFF, int PAIR = 0>
-__global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, Conv1Net n3, int nblk1) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, Conv1Net n3, int nblk1) {
     static_assert(!PAIR || DRL_CONV1_F16, "the two-weight-set form exists for the f16 path only");
     const bool second = PAIR != 1 && (int)blockIdx.x >= nblk1;         // block-uniform
     constexpr bool pair_blk = PAIR == 1;
@@ -180,22 +180,28 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
         if constexpr (OFF) return frame_off[b];
         else return (long long)b * 28224;
     };
-    uint2 bufa[8], bufb[8];
-    int b0, b1;
-    const int p0 = locate(t0, b0), p1 = locate(t0 + 1, b1);
-    const long long f0 = frame_base(b0);
-    long long fnext = frame_base(b1);
+    // THREE tile buffers: a wave computes tile t with the loads of t + 1 and t + 2 in flight (two buffers, one tile ahead:
+    // 21.2 -> 20.8 us at 1536 dense frames, 45.2 -> 40.1 us at 3840 = 5.2 TB/s; the two-weight-set launches of the R2D2
+    // step do not move: there 163 vector instructions + 30 MFMAs per tile keep the issue ports busy 55 % of the time,
+    // profiles/conv1_pair_pmc_r2.txt).
+    uint2 bufa[8], bufb[8], bufc[8];
+    int b0, b1, b2_;
+    const int p0 = locate(t0, b0), p1 = locate(t0 + 1, b1), p2_ = locate(t0 + 2, b2_);
+    const long long f0 = frame_base(b0), f1 = frame_base(b1);
+    long long fnext = frame_base(b2_);
 #pragma unroll
     for (int s = 0; s < 8; ++s) bufa[s] = *reinterpret_cast<const uint2*>(x + f0 + p0 + koff(s));
-    long long bnext = fnext + p1;
-    // one tile: prefetch tile+1 into `nxt`, compute `cur`. Called with the two buffers swapped (no register copies,
-    // and the compiler cannot sink the prefetch below the compute because both buffers are live).
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bufb[s] = *reinterpret_cast<const uint2*>(x + f1 + p1 + koff(s));
+    long long bnext = fnext + p2_;
+    // one tile: prefetch tile+2 into `nxt`, compute `cur`. Called with the three buffers rotated (no register copies,
+    // and the compiler cannot sink the prefetch below the compute because all buffers are live).
     auto body = [&](uint2 (&cur)[8], uint2 (&nxt)[8], int tile) __attribute__((always_inline)) {
         int b2;
-        const int p2 = locate(tile + 2, b2);
-        const long long f2 = frame_base(b2);                                                         // tile + 2 (first)
+        const int p2 = locate(tile + 3, b2);
+        const long long f2 = frame_base(b2);                                                         // tile + 3 (first)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + koff(s));    // tile + 1
+        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + koff(s));    // tile + 2
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
 #if DRL_CONV1_F16
         f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
@@ -245,11 +251,13 @@ __global__ __launch_bounds__(256) void k_conv1_direct(const uint8_t* __restrict_
         bnext = f2 + p2;
     };
     int tile = t0;
-    for (; tile + 1 < t1; tile += 2) {      // no skip path inside the loop: the back edge keeps exact vmcnt counts
-        body(bufa, bufb, tile);
+    for (; tile + 2 < t1; tile += 3) {      // no skip path inside the loop: the back edge keeps exact vmcnt counts
+        body(bufa, bufc, tile);
         body(bufb, bufa, tile + 1);
+        body(bufc, bufb, tile + 2);
     }
-    if (tile < t1) body(bufa, bufb, tile);  // odd tail
+    if (tile < t1) body(bufa, bufc, tile);          // tail of one or two tiles
+    if (tile + 1 < t1) body(bufb, bufa, tile + 1);
 }
 
 // tiles per wave so that at most `slots` waves are needed; returns the grid in *grid
