@@ -90,7 +90,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
 
 
 def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
-                           steps: Tuple[int, int], persistent: bool, prep=None) -> None:
+                           steps: Tuple[int, int], persistent: bool, prep=None, busy_tile: Optional[int] = None) -> None:
     """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target), each conv layer as one
     launch (the second network's read of a frame finds it in the Infinity Cache). net = (wb, wf, buf, bsum)."""
     t0, t1 = steps
@@ -114,7 +114,8 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
         # the input projections of BOTH networks as one launch: a forward chunk of one network alone leaves the 256 CUs
         # half empty (72 x 64 rows = 144 tiles of 256 x 256), two of them fill the chip
         H.gemm_big(H.NT, b1.act3[r0:r1], wb1.view("lstm.w_ih"), b1.xg.view(T * B, 4 * Hd)[r0:r1], bias=bs1,
-                   second=(b2.act3[r0:r1], wb2.view("lstm.w_ih"), b2.xg.view(T * B, 4 * Hd)[r0:r1], bs2, None))
+                   second=(b2.act3[r0:r1], wb2.view("lstm.w_ih"), b2.xg.view(T * B, 4 * Hd)[r0:r1], bs2, None),
+                   tile=busy_tile if t0 > 0 else None)
         return
     for wb, wf, buf, bsum in (net1, net2):
         xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
@@ -229,6 +230,12 @@ class R2D2Engine(ShardedIS):
         self.busy_aware = _os.environ.get("DRL_HALO_BUSY", "1") != "0"   # size persistent conv grids around the recurrences
         # row groups of the persistent BPTT (32 workgroups each; lstm_seq.hip): 80 steps alone take 366 / 270 / 271 us
         # with 1 / 2 / 4 groups
+        # tile of the W_ih forward product of the chunks that run next to a recurrence: 64 CUs hold a 64 KB workgroup each,
+        # a 256 x 256 tile (128 KB of LDS) cannot join them and the 240 tiles take two rounds on the 192 free CUs
+        # (93 -> 171 us); 128 x 128 tiles spread better: 1.846 -> 1.829 ms per step (profiles/r2d2_busy_tile_sweep_r2.txt)
+        self.busy_tile = int(_os.environ.get("DRL_BIG_TILE_BUSY", "3"))
+        if self.busy_tile < 0:
+            self.busy_tile = None
         self.bptt_groups = max(1, min(4, int(_os.environ.get("DRL_BPTT_GROUPS", "2"))))
         while self.bptt_groups > 1 and (self.B // 16) % self.bptt_groups:
             self.bptt_groups //= 2
@@ -324,7 +331,8 @@ class R2D2Engine(ShardedIS):
                     # from the second chunk on the torso runs next to the recurrence of the chunk before (64 workgroups)
                     with H.halo_busy(64 if (st_[0] > 0 and self.busy_aware) else 0):
                         seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
-                                               (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep)
+                                               (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep,
+                                               busy_tile=self.busy_tile)
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
                                       persistent=pl, prep=prep)
