@@ -90,7 +90,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
 
 
 def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
-                           steps: Tuple[int, int], persistent: bool, prep=None, busy_tile: Optional[int] = None) -> None:
+                           steps: Tuple[int, int], persistent: bool, prep=None, free_cus: int = 256) -> None:
     """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target), each conv layer as one
     launch (the second network's read of a frame finds it in the Infinity Cache). net = (wb, wf, buf, bsum)."""
     t0, t1 = steps
@@ -115,7 +115,7 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
         # half empty (72 x 64 rows = 144 tiles of 256 x 256), two of them fill the chip
         H.gemm_big(H.NT, b1.act3[r0:r1], wb1.view("lstm.w_ih"), b1.xg.view(T * B, 4 * Hd)[r0:r1], bias=bs1,
                    second=(b2.act3[r0:r1], wb2.view("lstm.w_ih"), b2.xg.view(T * B, 4 * Hd)[r0:r1], bs2, None),
-                   tile=busy_tile if t0 > 0 else None)
+                   cus=free_cus)
         return
     for wb, wf, buf, bsum in (net1, net2):
         xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
@@ -230,12 +230,10 @@ class R2D2Engine(ShardedIS):
         self.busy_aware = _os.environ.get("DRL_HALO_BUSY", "1") != "0"   # size persistent conv grids around the recurrences
         # row groups of the persistent BPTT (32 workgroups each; lstm_seq.hip): 80 steps alone take 366 / 270 / 271 us
         # with 1 / 2 / 4 groups
-        # tile of the W_ih forward product of the chunks that run next to a recurrence: 64 CUs hold a 64 KB workgroup each,
-        # a 256 x 256 tile (128 KB of LDS) cannot join them and the 240 tiles take two rounds on the 192 free CUs
-        # (93 -> 171 us); 128 x 128 tiles spread better: 1.846 -> 1.829 ms per step (profiles/r2d2_busy_tile_sweep_r2.txt)
-        self.busy_tile = int(_os.environ.get("DRL_BIG_TILE_BUSY", "3"))
-        if self.busy_tile < 0:
-            self.busy_tile = None
+        # the big products that run next to a recurrence count their tile rounds over the CUs it leaves free: 64 CUs hold
+        # a 64 KB workgroup each, no gemm_big tile (96-144 KB of LDS) fits beside one - 240 tiles of 256 x 256 take two
+        # rounds on 192 CUs (93 -> 171 us), 128 x 128 tiles spread better (profiles/r2d2_busy_tile_sweep_r2.txt)
+        self.big_busy_aware = _os.environ.get("DRL_BIG_BUSY_AWARE", "1") != "0"
         self.bptt_groups = max(1, min(4, int(_os.environ.get("DRL_BPTT_GROUPS", "2"))))
         while self.bptt_groups > 1 and (self.B // 16) % self.bptt_groups:
             self.bptt_groups //= 2
@@ -332,7 +330,7 @@ class R2D2Engine(ShardedIS):
                     with H.halo_busy(64 if (st_[0] > 0 and self.busy_aware) else 0):
                         seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
                                                (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep,
-                                               busy_tile=self.busy_tile)
+                                               free_cus=256 - 64 * self.fwd_groups_busy(st_))
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
                                       persistent=pl, prep=prep)
@@ -467,6 +465,10 @@ class R2D2Engine(ShardedIS):
             H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
         fj.join()
 
+    def fwd_groups_busy(self, st_) -> int:
+        """1 if the forward chunk ``st_`` runs next to the dual recurrence of the chunk before it (64 workgroups), else 0."""
+        return 1 if (st_[0] > 0 and self.big_busy_aware and self.persistent_lstm and self.dual_lstm) else 0
+
     def _torso_backward(self, k0: int, k1: int) -> None:
         """Backward of W_ih (input side) + conv3..conv1 for the time steps [k0, k1) of the backward window."""
         B, Hd, NB, r = self.B, self.Hd, self.NB, self.replay
@@ -481,7 +483,8 @@ class R2D2Engine(ShardedIS):
             H.lib_gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136))
             H.relu_mask(d3, a3, d3)                                 # the mask the fused epilogue would have applied
         elif H.use_big_gemm(n, 3136, 4 * Hd):
-            H.gemm_big(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), mask=a3)      # ReLU mask in the epilogue
+            busy_g = 32 * self.bptt_groups if (k0 > 0 and self.persistent_bptt and self.big_busy_aware) else 0
+            H.gemm_big(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), mask=a3, cus=256 - busy_g)   # ReLU mask in the epilogue
         else:
             H.gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), n, 3136, 4 * Hd, mask=a3, flags=H.EPI_MASK, big=False)
         # dX + dW + db of a conv layer = one launch (k_multi); from ~1000 frames the dX body is the LDS-halo kernel

@@ -297,14 +297,16 @@ BIG_GEMM = os.environ.get("DRL_BIG_GEMM", "1") != "0"
 BIG_GEMM_MIN_FLOP = 2.0e10
 
 
-def big_tile_for(M: int, N: int, nz: int = 1) -> int:
-    """Tile with the least (rounds over the 256 CUs) x (tile area) x (measured inefficiency of the smaller tiles: one
-    256 x 128 tile costs 0.64 of a 256 x 256 one, a 128 x 128 tile 0.36 - scripts/gemm_big_bench.py)."""
+def big_tile_for(M: int, N: int, nz: int = 1, cus: int = 256) -> int:
+    """Tile with the least (rounds over the CUs) x (tile area) x (measured inefficiency of the smaller tiles: one
+    256 x 128 tile costs 0.64 of a 256 x 256 one, a 128 x 128 tile 0.36 - scripts/gemm_big_bench.py). ``cus``: the CUs
+    that can take a workgroup - next to a persistent recurrence its 64 KB workgroups hold one CU each, and no tile of this
+    kernel (96-144 KB of LDS) fits beside them."""
     best, best_cost = 3, None
     for t, ineff in ((0, 1.0), (1, 1.27), (2, 1.27), (3, 1.44)):
         bm, bn = BIG_TILES[t]
         blocks = -(-M // bm) * -(-N // bn) * nz
-        cost = -(-blocks // 256) * bm * bn * ineff
+        cost = -(-blocks // max(1, cus)) * bm * bn * ineff
         if best_cost is None or cost < best_cost:
             best, best_cost = t, cost
     return best
@@ -315,11 +317,13 @@ def use_big_gemm(M: int, N: int, K: int) -> bool:
 
 
 def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None,
-             mask: Optional[torch.Tensor] = None, tile: Optional[int] = None, second=None, relu: bool = False) -> None:
+             mask: Optional[torch.Tensor] = None, tile: Optional[int] = None, second=None, relu: bool = False,
+             cus: int = 256) -> None:
     """c = a.b^T (NT: a [M,K], b [N,K]) | a.b (NN: a [M,K], b [K,N]) | a^T.b (TN: a [K,M], b [K,N]); a, b bf16 row-major
     2-D (row stride = shape[1]); c fp32 or bf16 [M,N]; ``bias`` fp32 [N] added, ``mask`` bf16 [M,N]: c = 0 where mask <= 0
     (ReLU backward), ``relu``: c = max(c, 0) after the bias - all in the epilogue, no second pass. ``second`` = (a2, b2, c2, bias2, mask2): a second problem of the
-    same shape in the same launch (two networks fill the 256 CUs together where each alone would not)."""
+    same shape in the same launch (two networks fill the 256 CUs together where each alone would not). ``cus``: CUs free
+    for this launch (the automatic tile choice counts its rounds over them, :func:`big_tile_for`)."""
     _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
     assert a.dim() == 2 and b.dim() == 2 and c.dim() == 2
     if mode == NT:
@@ -339,7 +343,7 @@ def gemm_big(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, bias:
         _chk(a2, torch.bfloat16, "a2"); _chk(b2, torch.bfloat16, "b2")
         assert a2.shape == a.shape and b2.shape == b.shape and c2.shape == c.shape and c2.dtype == c.dtype and c2.is_contiguous()
         assert (bias2 is None) == (bias is None) and (mask2 is None) == (mask is None)
-    t = big_tile_for(M, N, 2 if second is not None else 1) if tile is None else tile
+    t = big_tile_for(M, N, 2 if second is not None else 1, cus) if tile is None else tile
     _ck(native.hip().drl_gemm_big(mode, t, _p(a), a.shape[1], _p(b), b.shape[1], M, N, K, _p(c), N, _p(bias), _p(mask),
                                   N if mask is not None else 0, (1 if c.dtype == torch.float32 else 0) | (2 if relu else 0),
                                   _p(a2), _p(b2), _p(c2), _p(bias2), _p(mask2), _s()), "gemm_big")
