@@ -77,15 +77,18 @@ __device__ __forceinline__ void grid_arrive_fl(int* flags, int wg, int step_done
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1, int T, int M, int* err) {
+__global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1, int T, int M, int groups, int* err) {
     constexpr int NWG = 4 * HD / 64, NKS = HD / 32;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int net = blockIdx.x / NWG, wg = blockIdx.x % NWG;
+    // row groups as in k_lstm_bptt below: the M/16 row blocks are dealt to `groups` independent sets of NWG workgroups
+    // (blockDim.x / 64 row blocks each, own flags) - for launches that have the chip to themselves
+    const int net = blockIdx.x / (NWG * groups), grp = (blockIdx.x / NWG) % groups, wg = blockIdx.x % NWG;
     const LstmXNet a = net ? n1 : n0;
-    int* sync = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(a.hx) + HX_SYNC_BYTE_OFFSET);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g4 = lane >> 4;
-    for (int i = tid; i < 4 * NKS * 64; i += 256) {
+    int* sync = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(a.hx) + HX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * DRL_LSTM_FLAG_STRIDE);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g4 = lane >> 4;
+    const int wave = grp * (int)(blockDim.x >> 6) + (tid >> 6);      // row block [16 wave, 16 wave + 16) of the batch
+    for (int i = tid; i < 4 * NKS * 64; i += (int)blockDim.x) {
         const int l = i & 63, f = i >> 6, ks = f % NKS, nt = f / NKS, ii = l & 15;
         const int n = 64 * wg + 4 * (4 * (ii >> 2) + nt) + (ii & 3);
         *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = *reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + ks * 32 + (l >> 4) * 8);
@@ -175,18 +178,22 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
 }
 
 // hx0 / hx1: exchange buffers of 256 KB each (lstm_hx), zero when first used; nothing is reset between launches.
+// groups: 1, 2 or 4 independent row groups (must divide M / 16; 0 = 1).
 DRL_API int drl_lstm_seq_fwd_x(const float* xg0, const void* w0, void* hs0, float* cs0, void* gates0, const float* bias0, void* hx0,
                                 const float* xg1, const void* w1, void* hs1, float* cs1, void* gates1, const float* bias1, void* hx1, int n_nets,
-                                int T, int M, int H, int* err, hipStream_t s) {
+                                int T, int M, int H, int groups, int* err, hipStream_t s) {
     if (H != 512 || M <= 0 || M > 64 || (M & 15) || T <= 0 || n_nets < 1 || n_nets > 2 || !hx0 || (n_nets == 2 && !hx1)) return -1;
     if (T >= 4096) return -1;                                  // flags carry the step in 12 bits
+    const int rbs = M / 16;
+    if (groups <= 0) groups = 1;
+    if (groups > 4 || rbs % groups) return -1;
     LstmXNet a{xg0, (const bf16_t*)w0, (bf16_t*)hs0, cs0, (bf16_t*)gates0, bias0, (bf16_t*)hx0};
     LstmXNet b{xg1, (const bf16_t*)w1, (bf16_t*)hs1, cs1, (bf16_t*)gates1, bias1, (bf16_t*)hx1};
     constexpr int LDS = 4 * (512 / 32) * 1024;
     auto k0 = k_lstm_seq_fwd_x<512>;
     static bool once = (hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
     (void)once;
-    k0<<<n_nets * (4 * 512 / 64), 256, LDS, s>>>(a, b, T, M, err);
+    k0<<<n_nets * groups * (4 * 512 / 64), 64 * (rbs / groups), LDS, s>>>(a, b, T, M, groups, err);
     return (int)hipGetLastError();
 }
 

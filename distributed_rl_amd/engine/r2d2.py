@@ -234,6 +234,10 @@ class R2D2Engine(ShardedIS):
         # a 64 KB workgroup each, no gemm_big tile (96-144 KB of LDS) fits beside one - 240 tiles of 256 x 256 take two
         # rounds on 192 CUs (93 -> 171 us), 128 x 128 tiles spread better (profiles/r2d2_busy_tile_sweep_r2.txt)
         self.big_busy_aware = _os.environ.get("DRL_BIG_BUSY_AWARE", "1") != "0"
+        # the recurrence of the LAST forward chunk has the chip to itself: row groups (lstm_seq.hip) spread its h loads
+        self.fwd_groups_last = max(1, min(4, int(_os.environ.get("DRL_FWD_GROUPS_LAST", "2"))))
+        while self.fwd_groups_last > 1 and (self.B // 16) % self.fwd_groups_last:
+            self.fwd_groups_last //= 2
         self.bptt_groups = max(1, min(4, int(_os.environ.get("DRL_BPTT_GROUPS", "2"))))
         while self.bptt_groups > 1 and (self.B // 16) % self.bptt_groups:
             self.bptt_groups //= 2
@@ -349,7 +353,8 @@ class R2D2Engine(ShardedIS):
                         tg_net = (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1], None)
                         dfr = defer_xg_bias((t1 - t0) * B, Hd, True)
                         H.lstm_seq_fwd_x([on_net + (self.on.hx, self.bsum_on if dfr else None),
-                                          tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err)
+                                          tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err,
+                                         groups=self.fwd_groups_last if st_ is self.fwd_bounds[-1] else 1)
                 else:
                     with fj.fork(2):
                         seq_recurrence(T, B, Hd, self.Tb, self.tg, pl, steps=st_, bsum=self.bsum_tg)

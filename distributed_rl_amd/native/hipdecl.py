@@ -52,7 +52,7 @@ SIGS = {
     "drl_fc_bwd": [P, P, P, P, P, P, I, I, I, P, P, I, P, P, P, P, I, P],
     "drl_lstm_step": [P, P, P, P, P, P, P, I, I, P],
     # lstm_seq.hip
-    "drl_lstm_seq_fwd_x": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P],
+    "drl_lstm_seq_fwd_x": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P],
     "drl_lstm_bptt": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "drl_lstm_set_bptt_groups": [I],
     # lstm.hip

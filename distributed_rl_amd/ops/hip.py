@@ -743,12 +743,14 @@ def lstm_hx(device) -> torch.Tensor:
     return torch.zeros(32768, dtype=torch.int64, device=device)
 
 
-def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
+def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor, groups: int = 1) -> None:
     """Persistent recurrence (csrc/hip/lstm_seq.hip): ONE launch runs all T steps of 1 or 2 networks; h is handed between
     the workgroups through an exchange buffer laid out in consumer order. ``nets`` = list of (xg [T,M,4H] f32, w_hh [4H,H]
     bf16 gate-interleaved, hs [T+1,M,H] bf16, cs [T+1,M,H] f32, gates [T,M,4H] bf16 | None, hx) or (..., hx, bias);
     hs[0] / cs[0] hold the initial state; ``err`` (1 x int32) turns non-zero if an inter-workgroup wait expired. hx from :func:`lstm_hx` (one per network, not shared between launches
-    that may run at the same time); ``bias`` ([4H] fp32, gate-interleaved like xg's columns) is added to xg on the fly."""
+    that may run at the same time); ``bias`` ([4H] fp32, gate-interleaved like xg's columns) is added to xg on the fly.
+    ``groups`` (1, 2, 4, dividing M/16): independent row groups of 32 workgroups per network - same numbers, the h loads
+    of a step spread over more CUs (for launches that have the chip to themselves)."""
     assert 1 <= len(nets) <= 2
     _chk(err, torch.int32, "err")
     args = []
@@ -765,7 +767,7 @@ def lstm_seq_fwd_x(nets, T: int, M: int, Hd: int, err: torch.Tensor) -> None:
         args += [_p(xg), _p(w_hh), _p(hs), _p(cs), _p(gates), _p(bias), _p(hx)]
     if len(nets) == 1:
         args += [None] * 7
-    _ck(native.hip().drl_lstm_seq_fwd_x(*args, len(nets), T, M, Hd, _p(err), _s()), "lstm_seq_fwd_x")
+    _ck(native.hip().drl_lstm_seq_fwd_x(*args, len(nets), T, M, Hd, int(groups), _p(err), _s()), "lstm_seq_fwd_x")
 
 
 def lstm_bx(device) -> torch.Tensor:

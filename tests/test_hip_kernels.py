@@ -794,7 +794,7 @@ def test_lstm_step_and_persistent_sequence(hip, M):
     T, Hd = 12, 512
     w_k, xg_k, h0, c0, hs_ref, cs_ref = _lstm_case(T, M, Hd, 100 + M)
     outs = []
-    for mode in ("step", "xchg", "xchgx2"):
+    for mode in ("step", "xchg", "xchgx2", "xchg-g2", "xchgx2-g4"):
         hs = torch.zeros(T + 1, M, Hd, dtype=torch.bfloat16, device=DEV)
         cs = torch.zeros(T + 1, M, Hd, device=DEV)
         gates = torch.zeros(T, M, 4 * Hd, dtype=torch.bfloat16, device=DEV)
@@ -805,14 +805,19 @@ def test_lstm_step_and_persistent_sequence(hip, M):
         else:                                                       # persistent recurrence, one launch for all T steps
             err = torch.zeros(1, dtype=torch.int32, device=DEV)
             nets = [(xg_k, w_k, hs, cs, gates, H.lstm_hx(DEV))]
-            if mode == "xchgx2":                                    # second network in the same launch, no gates
+            if "x2" in mode:                                        # second network in the same launch, no gates
                 hs2, cs2 = hs.clone(), cs.clone()
                 nets.append((xg_k, w_k, hs2, cs2, None, H.lstm_hx(DEV)))
-            for _ in range(2):                                      # twice: the scratch is reused across launches
-                H.lstm_seq_fwd_x(nets, T, M, Hd, err)
+            groups = int(mode[-1]) if "-g" in mode else 1           # independent row groups (when they divide M / 16)
+            if (M // 16) % groups:
+                groups = 1
+            for rep in range(3):                                    # again: the scratch is reused across launches,
+                H.lstm_seq_fwd_x(nets, T, M, Hd, err, groups=groups if rep != 1 else 1)      # ... with changing splits
             assert int(err.item()) == 0
-            if mode == "xchgx2":
+            if "x2" in mode:
                 assert torch.equal(hs2, hs) and torch.equal(cs2, cs)
+            if "-g" in mode:                                        # same arithmetic in the same order as one group
+                assert torch.equal(hs.float().cpu(), outs[1][0]) and torch.equal(cs.cpu(), outs[1][1])
         torch.testing.assert_close(hs[1:].float().cpu(), hs_ref, rtol=3e-2, atol=3e-2)
         torch.testing.assert_close(cs[1:].cpu(), cs_ref, rtol=3e-2, atol=3e-2)
         outs.append((hs.float().cpu(), cs.cpu(), gates.float().cpu()))
