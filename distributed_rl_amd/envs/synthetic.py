@@ -66,6 +66,13 @@ class CatchVecEnv:
         return fr
 
     def _push_frame(self, idx, fr) -> None:
+        if idx is self._ar and self.stack == 4:
+            # all envs, 4-stack: a pixel's stack is one little-endian uint32 - dropping the oldest frame and appending the
+            # new one is a shift and an or over E x 7056 words (the strided byte copy below costs 10x as much)
+            o32 = self.obs.view(np.uint32)[..., 0]
+            np.right_shift(o32, 8, out=o32)
+            np.bitwise_or(o32, fr.astype(np.uint32) << 24, out=o32)
+            return
         self.obs[idx, :, :, :-1] = self.obs[idx, :, :, 1:]
         self.obs[idx, :, :, -1] = fr
 
