@@ -98,16 +98,23 @@ def launch_ranks(args, argv) -> int:
 
 
 # ---- one rank -------------------------------------------------------------------------------------------------------
-def timed(dist, fn, steps, warmup):
-    """W untimed steps, then exactly ``steps`` steps between barrier + synchronize on both sides; max over ranks."""
+def timed(dist, fn, steps, warmup, many=None):
+    """W untimed steps, then exactly ``steps`` steps between barrier + synchronize on both sides; max over ranks.
+    ``many(n)`` runs n steps in one call (ApexEngine.run_steps: several steps per graph replay, the same steps)."""
     import torch
-    for _ in range(warmup):
-        fn()
+    if many is not None:
+        many(warmup)
+    else:
+        for _ in range(warmup):
+            fn()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
+    if many is not None:
+        many(steps)
+    else:
+        for _ in range(steps):
+            fn()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -200,14 +207,15 @@ def run_rank(args) -> int:
 
     eng = eng_s = None
     eng = build_apex(rep, cfg)
-    dt = timed(dist, eng.step, args.steps, args.warmup)
+    dt = timed(dist, eng.step, args.steps, args.warmup, many=eng.run_steps)
     ms = 1e3 * dt / args.steps
     updates_s = args.steps / dt
     value = updates_s * args.batch * W
     st = eng.stats()                                       # raises if a bounded inter-GPU / inter-workgroup wait timed out
     extra.update({"apex_updates_per_s": updates_s, "loss": st["loss"], "grad_norm": st["grad_norm"],
                   "replay_items_per_gpu": cap, "replay_gb_per_gpu": round(rep.bytes_per_item() * cap / 1e9, 2),
-                  "graph": eng._graphs[0] if eng._graphs else "eager"})
+                  "graph": eng._graphs[0] if eng._graphs else "eager",
+                  "steps_per_graph_replay": eng.steps_per_graph if eng._graph_k is not None else 1})
     if W > 1:
         extra["grad_all_reduce"] = "direct xGMI kernel (in graph)" if dist.xgmi is not None else "process group (%s)" % dist.backend
         if dist.all_reduce_us is not None:                 # stand-alone us per all-reduce of the gradient buffer, both paths
@@ -221,7 +229,8 @@ def run_rank(args) -> int:
 
     if not args.no_extra:
         try:    # steady-state window (>= 0.5 s) of the same step, reported next to the --steps figure
-            s_per, n = steady(dist, eng.step, 100)
+            s_per, n = steady(dist, lambda: eng.run_steps(100), 1)
+            s_per, n = s_per / 100, n * 100
             eng.stats()
             extra["steady_ms_per_step"] = 1e3 * s_per
             extra["steady_steps"] = n
@@ -237,13 +246,13 @@ def run_rank(args) -> int:
             torch.cuda.empty_cache()
             bs = args.batch // W
             eng_s = build_apex(rep.with_batch(bs), ApexConfig(batch_size=bs))
-            s_dt = timed(dist, eng_s.step, args.steps, args.warmup)
+            s_dt = timed(dist, eng_s.step, args.steps, args.warmup, many=eng_s.run_steps)
             eng_s.stats()
             extra["strong_scaling"] = {"global_batch": args.batch, "batch_per_gpu": bs, "ms_per_step": 1e3 * s_dt / args.steps,
                                        "transitions_per_s": args.steps / s_dt * args.batch,
                                        "graph": eng_s._graphs[0] if eng_s._graphs else "eager"}
-            s_per, n = steady(dist, eng_s.step, 100)
-            extra["strong_scaling"]["steady_ms_per_step"] = 1e3 * s_per
+            s_per, n = steady(dist, lambda: eng_s.run_steps(100), 1)
+            extra["strong_scaling"]["steady_ms_per_step"] = 1e3 * s_per / 100
             eng = eng_s
         except Exception as e:  # noqa: BLE001
             extra["strong_scaling_error"] = repr(e)[:200]

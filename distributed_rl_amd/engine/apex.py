@@ -136,6 +136,8 @@ class ApexEngine(ShardedIS):
         self._primed = False                                              # True once a pre-drawn batch is waiting
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         self._graphs = None
+        self._graph_k = None
+        self.steps_per_graph = max(1, int(os.environ.get("DRL_STEPS_PER_GRAPH", "4")))
         self.steps_done = 0
         # a timed-out poll of the direct xGMI all-reduce must not reach the parameters (engine/guard.py)
         self.guard = StepGuard(dev)
@@ -259,6 +261,20 @@ class ApexEngine(ShardedIS):
             with capture_graph(g):
                 self._eager_step()
             self._graphs = ("one", g)
+            # ... and K consecutive steps as ONE graph for run_steps(): the boundary between two replays costs ~8 us on
+            # the GPU (0.2297 ms per step replayed one by one where its kernels take 0.2213), everything a step needs
+            # from the one before it is on the device (StepState, presampled batch, priorities)
+            if self.steps_per_graph > 1:
+                try:
+                    gk = torch.cuda.CUDAGraph()
+                    with capture_graph(gk):
+                        for _ in range(self.steps_per_graph):
+                            self._eager_step()
+                    self._graph_k = gk
+                except Exception as e:  # noqa: BLE001 - the one-step graph above is complete; run_steps() falls back to it
+                    self._graph_k = None
+                    if self.dist is not None:
+                        self.dist.fallbacks.append("steps_per_graph->1: %r" % (e,))
         elif self.overlap_comm:
             # default for multi-GPU: three graphs, the two RCCL all-reduces issued between them on RCCL's own stream
             # (the big one overlaps the conv-backward graph)
@@ -300,6 +316,27 @@ class ApexEngine(ShardedIS):
         self.steps_done += 1
         if self.steps_done % self.cfg.target_update == 0:
             self.sync_target()
+
+    def run_steps(self, n: int) -> None:
+        """``n`` learner steps, ``steps_per_graph`` at a time as one graph replay wherever no host-side duty (target sync,
+        shard-scalar refresh) falls strictly inside such a run; the rest through :meth:`step`. Same steps, same order."""
+        K = self.steps_per_graph
+        while n > 0:
+            gk = self._graph_k if (self.use_graph and self._graphs is not None) else None
+            s = self.steps_done
+            room = min(self.cfg.target_update - s % self.cfg.target_update,
+                       (self.shard_refresh - s % self.shard_refresh) if self._shard_on else K)
+            if gk is None or n < K or room < K:
+                self.step()                                  # (the first call captures)
+                n -= 1
+                continue
+            self.guard.check()
+            self._maybe_refresh_shard()
+            gk.replay()
+            self.steps_done += K
+            n -= K
+            if self.steps_done % self.cfg.target_update == 0:
+                self.sync_target()
 
     # ---- host-visible state ---------------------------------------------------------------------------
     def stats(self) -> dict:

@@ -121,6 +121,29 @@ def test_apex_engine_graph_equals_eager_and_learns():
     assert sum(losses[-40:]) < sum(losses[:40]), (losses[:40], losses[-40:])
 
 
+def test_apex_engine_run_steps_equals_single_steps():
+    """run_steps(n): several steps per graph replay (and single steps around target syncs / for the remainder) are the
+    same steps as n calls of step()."""
+    _, cfg, rep, e1 = _setup(seed=2, rms_eps=1e-2)
+    _, _, rep2, e2 = _setup(seed=2, rms_eps=1e-2)
+    e1.use_graph = e2.use_graph = True
+    e1.cfg.target_update = e2.cfg.target_update = 10     # a target sync inside the run: K-step replays must stop in front of it
+    n = 27
+    for _ in range(n):
+        e1.step()
+    e2.run_steps(n)                                      # 1 (captures: + 2 warm-up) + K-step replays + single steps
+    torch.cuda.synchronize()
+    assert e2._graph_k is not None and e2.steps_per_graph == 4
+    assert e1.steps_done == e2.steps_done == n + 2
+    assert e1.stats()["step"] == e2.stats()["step"] == n + 2
+    a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
+    d = float((a - b).norm() / a.norm())
+    print("run_steps-vs-step relative parameter distance: %.3e" % d)
+    assert torch.isfinite(a).all() and d < 5e-5          # same RNG stream, same data; only float atomics reorder
+    dt = float((e1.T.flat.cpu() - e2.T.flat.cpu()).norm() / e1.T.flat.cpu().norm())
+    assert dt < 5e-5                                     # the target copies were taken at the same steps
+
+
 def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
     """world_size 1 over real RCCL (DRL_FORCE_DIST=1): the 3-graph step with the two asynchronous all-reduces hidden
     under the conv backward must train exactly like the single-graph step (an all-reduce over one rank is identity)."""
