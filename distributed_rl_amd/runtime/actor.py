@@ -184,6 +184,7 @@ class Actor:
             if os.environ.get("DRL_PLANE_BLOCKS", "1") != "0":
                 self.plane_log = PlaneLog(self.E, cap=4 * (cfg.actor_batch + cfg.nstep + 8) + 64)
                 self.local = _LocalPlaneBuffer(self.E, max(2 * cfg.actor_batch, min(cfg.actor_local_capacity, 256)))
+                self.asm.store_states = False             # the frames live in the plane log: positions only from here on
         self.env_steps = 0
         self.published_blocks = 0
         self.dropped_blocks = 0
