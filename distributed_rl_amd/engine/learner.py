@@ -126,7 +126,10 @@ class HipLearner:
         self._pub = None
         if self.device.type == "cuda" and os.environ.get("DRL_ASYNC_INGEST", "1") != "0":
             from .ingest import AsyncIngest
-            self.pipe = AsyncIngest(exp, self.replay, self.device)
+            # staging buffers in flight: a block lives ~7 learner steps between its retire and its commit (one more step
+            # launch, the host's run-ahead, the DMA), so 4 buffers capped the ingest at ~0.5 blocks per learner step - at
+            # 100 K transitions/s the actors of the system bench were waiting for ring slots
+            self.pipe = AsyncIngest(exp, self.replay, self.device, depth=int(os.environ.get("DRL_INGEST_DEPTH", "16")))
             self._pub = _AsyncPublisher(self.engine.P.flat, params)
         if self.metrics is None:
             from ..obs import Metrics
