@@ -63,6 +63,35 @@ def test_an_env_that_does_not_stack_is_stored_exactly_just_not_compressed():
     assert log.head.sum() >= 4 * 2 * 60 * E                       # every observation (s and s' differ here) entered whole
 
 
+def test_assembler_without_state_copies_emits_the_same_positions():
+    """store_states=False (the actor's setting once a PlaneLog keeps the frames): identical actions / returns / dones / envs /
+    positions, no observation copied into the batches."""
+    E, n = 5, 3
+    env = CatchVecEnv(E, seed=4, lives=1)
+    a1, a2 = VecNStepAssembler(E, n, 0.99), VecNStepAssembler(E, n, 0.99, store_states=False)
+    log = PlaneLog(E, cap=64)
+    env.reset()
+    rng = np.random.default_rng(1)
+    emitted = 0
+    for _ in range(200):
+        obs = env.current_obs()
+        qs = log.observe(obs)
+        act = rng.integers(0, 4, E)
+        nxt, r, d, _ = env.step(act)
+        qn = log.observe(nxt)
+        o1, o2 = a1.step(obs, act, r, nxt, d, qs, qn), a2.step(obs, act, r, nxt, d, qs, qn)
+        assert (o1 is None) == (o2 is None)
+        if o1 is None:
+            continue
+        assert o2.state is None and o2.next_state is None
+        for f in ("action", "reward", "done", "env", "qs", "qs2"):
+            assert np.array_equal(getattr(o1, f), getattr(o2, f)), f
+        emitted += len(o1.env)
+    assert emitted > 800
+    with pytest.raises(AssertionError):
+        a2.step(obs, act, r, nxt, d)                              # no positions, no states: nothing to emit from
+
+
 def test_plane_log_refuses_positions_it_no_longer_holds():
     log = PlaneLog(1, cap=8)
     obs = np.zeros((1, 84, 84, 4), np.uint8)
