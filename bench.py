@@ -31,6 +31,9 @@ PAPER_APEX_TRANSITIONS_PER_S = 9700.0     # ~19 batches/s x 512 (re
 PAPER_R2D2_UPDATES_PER_S = 5.0
 PAPER_ACTOR_FPS = 50000.0
 PAPER_R2D2_ACTOR_FPS = 66000.0             # 256 actors x ~260 fps (recalled from Kapturowski et al. 2019)
+_RANK_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+             "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RESTART_COUNT",
+             "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE")
 MIN_WINDOW_S = 0.5                         # every loop is also measured over a steady-state window at least this long
 
 
@@ -258,20 +261,41 @@ def run_rank(args) -> int:
             extra["strong_scaling_error"] = repr(e)[:200]
 
     if not args.no_extra:
-        if W == 1:      # actor inference: one GPU's worth (the actors of a multi-GPU run are separate processes)
-            try:
-                from distributed_rl_amd.engine.actor import ActorEngine
-                act = ActorEngine(args.n_action, args.actor_envs, dev, params=eng)
-                a_s, n = steady(dist, act.step_host, 50)            # pinned H2D frames + inference + D2H actions
-                extra["actor_env_frames_per_s"] = 4 * args.actor_envs / a_s          # frameskip 4
-                extra["actor_inferences_per_s"] = args.actor_envs / a_s
-                extra["actor_vs_paper"] = extra["actor_env_frames_per_s"] / PAPER_ACTOR_FPS
-                g_s, n = steady(dist, act.step_synthetic, 50)       # device-resident frames (no PCIe)
-                extra["actor_inferences_per_s_device_resident"] = args.actor_envs / g_s
-                extra["actor_note"] = "inference only (H2D + forward + eps-greedy + D2H); the actor LOOP rate is system_*"
-                del act
-            except Exception as e:  # side metric only
-                extra["actor_error"] = repr(e)[:200]
+        try:    # actor inference on EVERY rank's GPU (N > 1: per-GPU minimum and the node's aggregate)
+            from distributed_rl_amd.engine.actor import ActorEngine
+            act = ActorEngine(args.n_action, args.actor_envs, dev, params=eng)
+            a_s, n = steady(dist, act.step_host, 50)            # pinned H2D frames + inference + D2H actions
+            extra["actor_env_frames_per_s"] = 4 * args.actor_envs / a_s * W      # frameskip 4; all ranks act at once
+            extra["actor_env_frames_per_s_per_gpu"] = 4 * args.actor_envs / a_s  # a_s is the slowest rank's time per call
+            extra["actor_inferences_per_s"] = args.actor_envs / a_s * W
+            extra["actor_vs_paper"] = extra["actor_env_frames_per_s"] / PAPER_ACTOR_FPS
+            g_s, n = steady(dist, act.step_synthetic, 50)       # device-resident frames (no PCIe)
+            extra["actor_inferences_per_s_device_resident"] = args.actor_envs / g_s * W
+            extra["actor_note"] = "inference only (H2D + forward + eps-greedy + D2H), %d GPU(s) at once; the actor LOOP " \
+                                  "rate is system_*" % W
+            del act
+        except Exception as e:  # side metric only
+            extra["actor_error"] = repr(e)[:200]
+        if W > 1:
+            try:    # learner -> actor GPUs: broadcast of the flat fp32 parameters, device to device over the process group
+                import torch.distributed as td
+                pb = {}
+                for name, numel in (("apex_13MB", eng.P.flat.numel()), ("r2d2_32MB", r2d2_layout(args.n_action).total)):
+                    buf = torch.zeros(numel, device=dev)
+                    for _ in range(3):
+                        td.broadcast(buf, src=0)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        td.broadcast(buf, src=0)
+                    torch.cuda.synchronize()
+                    pb[name] = round(dist.max_scalar((time.perf_counter() - t0) / 20 * 1e6), 1)
+                    del buf
+                pb["backend"] = dist.backend
+                extra["param_broadcast_us"] = pb
+            except Exception as e:  # noqa: BLE001
+                extra["param_broadcast_error"] = repr(e)[:200]
         try:
             eng = rep = eng_s = None
             dist.release_grad_buffer()
@@ -304,13 +328,13 @@ def run_rank(args) -> int:
             reng = srep = None
             dist.release_grad_buffer()
             torch.cuda.empty_cache()
-            if W == 1:
-                from distributed_rl_amd.engine.r2d2_actor import R2D2ActorEngine
-                ract = R2D2ActorEngine(args.n_action, args.actor_envs, rcfg, dev)
-                ra_s, n = steady(dist, ract.step_host, 25)      # recurrent actor: frames in over PCIe, actions out
-                extra["r2d2_actor_env_frames_per_s"] = 4 * args.actor_envs / ra_s
-                extra["r2d2_actor_vs_paper"] = extra["r2d2_actor_env_frames_per_s"] / PAPER_R2D2_ACTOR_FPS
-                del ract
+            from distributed_rl_amd.engine.r2d2_actor import R2D2ActorEngine
+            ract = R2D2ActorEngine(args.n_action, args.actor_envs, rcfg, dev)
+            ra_s, n = steady(dist, ract.step_host, 25)      # recurrent actor: frames in over PCIe, actions out
+            extra["r2d2_actor_env_frames_per_s"] = 4 * args.actor_envs / ra_s * W
+            extra["r2d2_actor_env_frames_per_s_per_gpu"] = 4 * args.actor_envs / ra_s
+            extra["r2d2_actor_vs_paper"] = extra["r2d2_actor_env_frames_per_s"] / PAPER_R2D2_ACTOR_FPS
+            del ract
         except Exception as e:
             extra["r2d2_error"] = repr(e)[:200]
 
@@ -332,6 +356,23 @@ def run_rank(args) -> int:
                 extra["system_" + algo] = json.loads(last[-1]) if last else {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:  # noqa: BLE001
                 extra["system_" + algo] = {"error": repr(e)[:200]}
+    if not args.no_system and not args.no_extra and world > 1:
+        # whole system on the multi-GPU node, through the launcher (what ./run.sh starts): data-parallel learner ranks +
+        # placed actors, (a) co-located on every GPU, (b) learner GPUs | actor GPUs with RCCL parameter broadcast lanes.
+        # The other ranks have left by the time these children need the GPUs: rank 0 waits for them to exit first.
+        if rank != 0:
+            return 0
+        torch.cuda.empty_cache()
+        time.sleep(3.0)
+        for mode in ("colocated", "split"):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "system_dp_bench.py"), "--gpus", str(world),
+                                    "--mode", mode, "--seconds", str(args.system_seconds)], capture_output=True, text=True,
+                                   timeout=200, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in _RANK_ENV})
+                last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                extra["system_dp_" + mode] = json.loads(last[-1]) if last else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:  # noqa: BLE001
+                extra["system_dp_" + mode] = {"error": repr(e)[:200]}
 
     if rank == 0:
         print(json.dumps({

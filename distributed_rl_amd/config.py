@@ -119,6 +119,9 @@ class LaunchConf:
     transport: str = "shm"           # shm | redis | inproc  (new key)
     num_envs: int = 1                # envs per actor process (new key)
     learner_gpus: int = 1            # data-parallel learner ranks on this node, one per GPU (new key)
+    learner_devices: str = ""        # GPU ordinals of the learner ranks, e.g. "0,1,2,3" ('' = 0..learner_gpus-1) (new key)
+    actor_gpus: str = ""             # GPU ordinals the actors run on, e.g. "4,5,6,7"; '' = the GPU of the learner rank whose
+                                     # shard the actor feeds (runtime/placement.py) (new key)
     param_channel: str = ""          # "" = same as transport | "collective" = torch.distributed broadcast (new key)
     param_backend: str = "gloo"      # backend of the collective parameter channel: gloo | nccl (= RCCL, one GPU per process)
     run_dir: str = ""                # where shm names / heartbeats / logs live (new key)

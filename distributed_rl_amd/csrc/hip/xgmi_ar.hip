@@ -43,25 +43,40 @@ struct XarCtx {
     void* opened[XAR_MAX_W][2];
 };
 
+// One inter-GPU barrier of block b with block b of every peer. What makes it a hand-off of DATA (not only of control),
+// in the order the instructions must appear in the ISA (checked in the .s; hipcc leaves out both waits on its own):
+//   1. EVERY wave waits for its own stores (s_waitcnt vmcnt(0)): a workgroup-scope barrier does not wait for vector
+//      memory on gfx950 (one CU, one L1), so without this the signalling wave could release before its siblings' stores
+//      have reached the L2 it writes back;
+//   2. block barrier, then ONE wave: system-scope release fence (buffer_wbl2 sc0 sc1: the XCD's L2 goes to memory) and
+//      an explicit s_waitcnt vmcnt(0) - the compiler drops the fence's own wait when the counter is provably zero, and
+//      the flag would overtake the write-back;
+//   3. relaxed system-scope flag stores into the peers' flag blocks (uncached memory), relaxed polls of the local block,
+//      then ONE system-scope acquire fence (buffer_inv sc0 sc1: L1 and the L2's lines of peer memory) + its wait, and the
+//      block barrier that lets the other waves load.
 __device__ __forceinline__ void xar_barrier(const XarPeers& P, int ch, int phase, int rank, int W, uint32_t epoch, int* err,
                                             long long timeout_ticks) {
-    // every thread's earlier stores have left the wave (vmcnt) before the block barrier; the release below then writes
-    // the L2 back before the flag becomes visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < W && t != rank) {
-        const int b = blockIdx.x;
-        uint32_t* remote = P.flags[t] + ((ch * 3 + phase) * XAR_MAX_W + rank) * XAR_MAX_B + b;
-        __hip_atomic_store(remote, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint32_t* local = P.flags[rank] + ((ch * 3 + phase) * XAR_MAX_W + t) * XAR_MAX_B + b;
-        const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(local, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-            if (wall_clock64() - t0 > timeout_ticks) { *err = 1 + phase; break; }
-            __builtin_amdgcn_s_sleep(4);
+    if (t < WAVE) {                                    // wave 0 (wave-uniform branch): lanes 0..W-1 each serve one peer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t < W && t != rank) {
+            const int b = blockIdx.x;
+            uint32_t* remote = P.flags[t] + ((ch * 3 + phase) * XAR_MAX_W + rank) * XAR_MAX_B + b;
+            __hip_atomic_store(remote, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t* local = P.flags[rank] + ((ch * 3 + phase) * XAR_MAX_W + t) * XAR_MAX_B + b;
+            const long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+                if (wall_clock64() - t0 > timeout_ticks) { *err = 1 + phase; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);           // system scope, every wave: drop stale lines of peer memory
 }
 
 // grid = n_blocks (the same on every rank), block = XAR_THREADS. off4 / n4 in float4 units.
@@ -109,7 +124,11 @@ __global__ __launch_bounds__(XAR_THREADS) void k_xgmi_all_reduce(XarPeers P, int
 #define XAR_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // Allocates the communication buffer (cap_elems floats, zeroed), the flag block and the epoch counters on the current device.
-DRL_API int drl_xar_create(int rank, int world, long long cap_elems, int n_blocks, double timeout_s, void** out) {
+// mem_kind: where the DATA buffer lives. 0 = ordinary (coarse-grained) device memory: cached in the owner's L2, peers see
+// it after the release / acquire pairs of xar_barrier; 1 = fine-grained, 2 = uncached device memory: coherent without
+// any cache maintenance - the fallback parallel/dist.py switches to when the default fails its verification on a node
+// (the engines' own kernels then write their gradients through the L2: slower steps, same numbers).
+DRL_API int drl_xar_create2(int rank, int world, long long cap_elems, int n_blocks, double timeout_s, int mem_kind, void** out) {
     if (world < 1 || world > XAR_MAX_W || rank < 0 || rank >= world || n_blocks < 1 || n_blocks > XAR_MAX_B || cap_elems <= 0 ||
         (cap_elems & 3))
         return -1;
@@ -118,7 +137,10 @@ DRL_API int drl_xar_create(int rank, int world, long long cap_elems, int n_block
     c->timeout_ticks = (long long)(timeout_s * 1.0e8);                 // wall_clock64: constant 100 MHz
     XAR_CK(hipGetDevice(&c->device));
     void* d = nullptr; void* f = nullptr;
-    XAR_CK(hipMalloc(&d, (size_t)cap_elems * 4));
+    if (mem_kind == 1) { XAR_CK(hipExtMallocWithFlags(&d, (size_t)cap_elems * 4, hipDeviceMallocFinegrained)); }
+    else if (mem_kind == 2) { XAR_CK(hipExtMallocWithFlags(&d, (size_t)cap_elems * 4, hipDeviceMallocUncached)); }
+    else if (mem_kind == 0) { XAR_CK(hipMalloc(&d, (size_t)cap_elems * 4)); }
+    else return -1;
     XAR_CK(hipMemset(d, 0, (size_t)cap_elems * 4));
     XAR_CK(hipExtMallocWithFlags(&f, XAR_FLAG_WORDS * 4, hipDeviceMallocUncached));
     XAR_CK(hipMemset(f, 0, XAR_FLAG_WORDS * 4));
@@ -130,6 +152,19 @@ DRL_API int drl_xar_create(int rank, int world, long long cap_elems, int n_block
     c->peers.data[rank] = (float*)d;
     c->peers.flags[rank] = (uint32_t*)f;
     *out = c;
+    return 0;
+}
+
+DRL_API int drl_xar_create(int rank, int world, long long cap_elems, int n_blocks, double timeout_s, void** out) {
+    return drl_xar_create2(rank, world, cap_elems, n_blocks, timeout_s, 0, out);
+}
+
+// Workgroups per collective from the next launch on. Every rank must switch at the same point of its launch sequence
+// (block b pairs with block b of the peers); the per-block epochs stay consistent because all ranks always launch the
+// same grid for the same collective.
+DRL_API int drl_xar_set_blocks(void* ctx, int n_blocks) {
+    if (n_blocks < 1 || n_blocks > XAR_MAX_B) return -1;
+    ((XarCtx*)ctx)->n_blocks = n_blocks;
     return 0;
 }
 

@@ -209,6 +209,13 @@ class ApexEngine(ShardedIS):
         self.guard.mirror()
         self._primed = self.presample
 
+    def redraw(self) -> None:
+        """Draw the waiting (pre-sampled) batch again, eagerly. For callers that turned the ingest machinery over WITHOUT
+        a learner step in between (``AsyncIngest.flush`` before a replay snapshot): slots of the waiting batch may have
+        been retired and rewritten meanwhile, and the captured step starts from the batch it finds in the live buffers."""
+        if self.presample and self._primed:
+            self.replay.sample(self.st, begin=True, is_n_scale=1.0, n_is=self.n_is)
+
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
             self.dist.all_reduce_flat(self.G.flat)

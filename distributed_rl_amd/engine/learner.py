@@ -27,14 +27,20 @@ from ..transport import ExperienceChannel, ParamChannel
 
 class _AsyncPublisher:
     """Parameter publication off the learner's critical path: ``publish()`` snapshots the flat fp32 parameters with one
-    D2D copy on the learner stream (a consistent version, ~10 us), a side stream moves the snapshot into pinned memory
-    and a thread writes it into the parameter channel once that copy has completed. A publication that is still in
-    flight is not queued behind: the register is a latest-value register, the next period publishes."""
+    D2D copy on the learner stream (a consistent version, ~10 us); a side stream takes it from there and a thread hands
+    it to the parameter channel once the stream work has completed. What the side stream does depends on what the
+    channel asks for (transport.ParamChannel.wants_host / wants_device): a register in shared memory needs a host copy
+    (D2H into pinned memory), a broadcast lane over RCCL takes the DEVICE snapshot as it is - no PCIe at all
+    (reference: ``SET params`` of a state_dict moved to the actor device, ape_x/learner.py:83-84). A publication that
+    is still in flight is not queued behind: the channel is a latest-value register, the next period
+    publishes."""
 
     def __init__(self, flat: torch.Tensor, params: ParamChannel):
         self.flat, self.params = flat, params
         self.snap = torch.empty_like(flat)
-        self.host = torch.empty(flat.numel(), dtype=torch.float32).pin_memory()
+        self.want_host = bool(getattr(params, "wants_host", True))
+        self.want_dev = bool(getattr(params, "wants_device", False))
+        self.host = torch.empty(flat.numel(), dtype=torch.float32).pin_memory() if self.want_host else None
         self.stream = torch.cuda.Stream(flat.device)
         self._busy = threading.Event()
         self._go = threading.Event()
@@ -43,10 +49,13 @@ class _AsyncPublisher:
         self.version = 0
         self.skipped = 0
         self.error = None
+        self.last_us = 0.0                 # wall clock of the channel's part of the last publication
         self._th = threading.Thread(target=self._run, name="drl-publish", daemon=True)
         self._th.start()
 
     def _run(self) -> None:
+        if self.flat.is_cuda:
+            torch.cuda.set_device(self.flat.device)
         while True:
             self._go.wait()
             self._go.clear()
@@ -54,7 +63,12 @@ class _AsyncPublisher:
                 return
             try:
                 self._done_ev.synchronize()
-                self.version = self.params.publish(self.host.numpy())
+                t0 = time.perf_counter()
+                with torch.cuda.stream(self.stream):         # collectives of a lane are ordered on OUR side stream
+                    self.version = self.params.publish2(self.host.numpy() if self.want_host else None,
+                                                        self.snap if self.want_dev else None)
+                self.stream.synchronize()                    # the snapshot is free again only when the lanes have read it
+                self.last_us = (time.perf_counter() - t0) * 1e6
             except BaseException as e:  # noqa: BLE001
                 self.error = e
             finally:
@@ -76,7 +90,8 @@ class _AsyncPublisher:
         ev.record(cur)
         self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
-            self.host.copy_(self.snap, non_blocking=True)
+            if self.want_host:
+                self.host.copy_(self.snap, non_blocking=True)
             self._done_ev = torch.cuda.Event()
             self._done_ev.record(self.stream)
         self._go.set()
@@ -171,7 +186,9 @@ class HipLearner:
         self._last_pub = time.time()
         if self._pub is not None:
             return self._pub.publish(wait=wait)
-        return self.params.publish(self.engine.P.flat.cpu().numpy())
+        flat = self.engine.P.flat
+        return self.params.publish2(flat.cpu().numpy() if getattr(self.params, "wants_host", True) else None,
+                                    flat if getattr(self.params, "wants_device", False) else None)
 
     def close(self) -> None:
         if self.pipe is not None:
@@ -179,20 +196,34 @@ class HipLearner:
         if self._pub is not None:
             self._pub.close()
 
+    def _replay_path(self, path: str) -> str:
+        """Sidecar of this rank's replay shard: ``model_<t>.replay.pth`` for a single learner / rank 0,
+        ``model_<t>.replay.r<k>.pth`` for the other data-parallel ranks (every rank owns a different shard)."""
+        r = self.dist.rank if self.dist is not None else 0
+        return path[:-4] + (".replay.pth" if r == 0 else ".replay.r%d.pth" % r)
+
     def save(self, save_dir: str) -> str:
+        """Data-parallel learners call this TOGETHER: weights, optimizer moments and the step state are identical on
+        every rank, so rank 0 alone writes them (the reference's ``model_<t>.pth``, learner.py:96-98); with
+        ``--save-replay`` every rank writes its own shard."""
         os.makedirs(save_dir, exist_ok=True)
         path = os.path.join(save_dir, "model_%d.pth" % self.step)
-        torch.save(self.engine.state_dict(), path)                      # reference format (learner.py:98)
         e = self.engine
-        aux = dict(step=self.step, engine="hip", algorithm=self.algorithm,
-                   target_flat=(e.T if not self.is_r2d2 else e.Tg).flat.cpu(),
-                   opt_flat=[t.flat.cpu() for t in ((e.SQ,) if not self.is_r2d2 else (e.M1, e.M2))],
-                   step_state=e.st.cpu())
-        torch.save(aux, path[:-4] + ".aux.pth")
+        if self.dist is None or self.dist.rank == 0:                        # one writer
+            torch.save(self.engine.state_dict(), path)                      # reference format (learner.py:98)
+            aux = dict(step=self.step, engine="hip", algorithm=self.algorithm,
+                       target_flat=(e.T if not self.is_r2d2 else e.Tg).flat.cpu(),
+                       opt_flat=[t.flat.cpu() for t in ((e.SQ,) if not self.is_r2d2 else (e.M1, e.M2))],
+                       step_state=e.st.cpu())
+            torch.save(aux, path[:-4] + ".aux.pth")
         if self.save_replay:
             if self.pipe is not None:
                 self.pipe.flush()                                           # blocks in flight become part of the snapshot
-            torch.save(self.replay.snapshot(), path[:-4] + ".replay.pth")
+                # flush() turned the ingest machinery over without a learner step in between: a batch drawn before it may
+                # point at slots that were retired and rewritten meanwhile, so the next step draws afresh (ADVICE r2)
+                if hasattr(e, "redraw"):
+                    e.redraw()
+            torch.save(self.replay.snapshot(), self._replay_path(path))
         return path
 
     def resume(self, path: str) -> int:
@@ -215,15 +246,17 @@ class HipLearner:
         else:
             e.sync_target()
         e.steps_done = self.step
-        rp = path[:-4] + ".replay.pth"
+        rp = self._replay_path(path)
         if os.path.exists(rp):                                              # plain tensors only: nothing is executed on load
             n = self.replay.restore(torch.load(rp, map_location="cpu", weights_only=True, mmap=True))
             self.ingested += n
         return self.step
 
-    def wait_memory(self, n: int, timeout: Optional[float] = None) -> bool:
+    def wait_memory(self, n: int, timeout: Optional[float] = None, stop_event=None) -> bool:
         t0 = time.time()
         while len(self.replay) <= n:
+            if stop_event is not None and stop_event.is_set():
+                return False
             if self.ingest(64) == 0:
                 time.sleep(0.001 if self.pipe is not None else 0.01)
             if timeout is not None and time.time() - t0 > timeout:
@@ -236,7 +269,9 @@ class HipLearner:
     def optimize_loop(self, max_steps: Optional[int] = None, save_model_dir: str = "./models", stop_event=None,
                       warmup_timeout: Optional[float] = None) -> int:
         cfg = self.cfg
-        if not self.wait_memory(max(cfg.batch_size, cfg.start_memory_size), warmup_timeout):
+        if not self.wait_memory(max(cfg.batch_size, cfg.start_memory_size), warmup_timeout, stop_event):
+            if stop_event is not None and stop_event.is_set():
+                return self.step                                  # asked to stop before learning started
             raise TimeoutError("replay never reached the learn-start size")
         if self.dist is not None:
             # shards fill at different rates; the steps that follow contain collectives with bounded waits (the direct
@@ -245,9 +280,17 @@ class HipLearner:
         end = None if max_steps is None else self.step + max_steps
         t_last, n_last, i_last = time.time(), self.step, self.ingested
         inflight = deque()
+        dp = self.dist is not None and self.dist.enabled
+        stop_period = int(os.environ.get("DRL_STOP_CHECK_STEPS", "200"))
         while end is None or self.step < end:
-            if stop_event is not None and stop_event.is_set():
-                break
+            if stop_event is not None:
+                # data-parallel ranks leave the loop TOGETHER (the step contains collectives): the request is agreed on
+                # every stop_period steps; a single learner looks at its own flag every step
+                if dp:
+                    if self.step % stop_period == 0 and self.dist.any_true(stop_event.is_set()):
+                        break
+                elif stop_event.is_set():
+                    break
             t = self.step
             ph = self.metrics_local.phase
             with ph("learner/ingest"):
@@ -279,7 +322,7 @@ class HipLearner:
                 t_last, n_last, i_last = now, t, self.ingested
                 if self.heartbeat is not None:
                     self.heartbeat.tick(t)
-            if t % cfg.save_timing == 0 and (self.dist is None or self.dist.rank == 0):        # one writer
+            if t % cfg.save_timing == 0:
                 with ph("learner/save"):
                     self.save(save_model_dir)
             self.step += 1
@@ -299,9 +342,9 @@ class HipLearner:
             m.scalar("Phase ms %s" % name, t, rep["mean_ms"], force=True)
 
 
-def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
-    from ..parallel.dist import Dist
-    dist = Dist(device=device) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=None) -> int:
+    """``dist``: the data-parallel learners' group (runtime/nodes.py builds it from the launcher's world or from
+    torch.distributed.run's environment); None = a single learner."""
     seed_ = (args.seed or 0) + (dist.rank if dist is not None else 0)      # every shard samples its own stream
     learner = HipLearner(args.algorithm, n_action, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb, dist=dist,
                          seed=seed_, save_replay=getattr(args, "save_replay", False))
@@ -313,8 +356,16 @@ def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device) -> int:
     if args.resume:
         learner.resume(args.resume)
     learner.publish(wait=True)
+    # SIGTERM (the launcher's teardown, --timeout): leave the loop at a step boundary - agreed on by all data-parallel
+    # ranks - instead of dying inside a step whose peers then wait for this rank's part of a collective
+    import signal
+    stop = threading.Event()
     try:
-        learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir)
+        signal.signal(signal.SIGTERM, lambda *_: stop.set())
+    except ValueError:                                                     # not the main thread (tests)
+        pass
+    try:
+        learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir, stop_event=stop)
     except KeyboardInterrupt:
         pass
     finally:

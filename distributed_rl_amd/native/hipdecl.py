@@ -67,6 +67,8 @@ SIGS = {
     "drl_relu_mask": [P, P, P, L, P],
     # xgmi_ar.hip
     "drl_xar_create": [I, I, L, I, c_double, POINTER(c_void_p)],
+    "drl_xar_create2": [I, I, L, I, c_double, I, POINTER(c_void_p)],
+    "drl_xar_set_blocks": [P, I],
     "drl_xar_handles": [P, P],
     "drl_xar_open": [P, I, P, I],
     "drl_xar_all_reduce": [P, L, L, I, P],

@@ -37,11 +37,21 @@ class _StreamWork:
 
 
 class Dist:
-    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: int = 600):
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: int = 600,
+                 group=None):
+        """``group`` = an existing sub-group of an initialised world (parallel/world.py: the data-parallel learners of a
+        launcher run that also holds actor ranks): rank / size are then the group's, and every collective of this object
+        stays inside it. Without it the default group is used, initialised here from RANK / WORLD_SIZE if need be."""
         import datetime
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.group = group
+        if group is not None:
+            self.rank, self.world_size = td.get_rank(group), td.get_world_size(group)
+            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            backend = backend or td.get_backend(group)
+        else:
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if device is None:
             if torch.cuda.is_available():
                 # DRL_SHARE_GPU=1: rehearse W ranks on fewer GPUs (ranks share devices round-robin; RCCL refuses that, so
@@ -61,7 +71,8 @@ class Dist:
         self.xgmi_reserve_numel = 0                            # make the direct all-reduce's buffer at least this large
         self.fallbacks = []                                    # every degraded path taken, for the bench's JSON line
         self.all_reduce_us = None                              # {"direct_xgmi": us, "process_group": us} measured by grad_buffer()
-        if self.enabled and not td.is_initialized():
+        self._owns_world = group is None                       # close() tears the default group down, never a caller's
+        if self.enabled and group is None and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             kw = {}
@@ -95,41 +106,58 @@ class Dist:
         if not usable:
             return None
         self._xgmi_tried = True
-        ar, why, ok = None, "", False
         cap = max(int(numel), int(self.xgmi_reserve_numel))
-        try:
-            import socket
-            hosts = [None] * self.world_size
-            td.all_gather_object(hosts, socket.gethostname())
-            if len(set(hosts)) != 1:
-                raise RuntimeError("ranks on different hosts")
-            from .xgmi import XgmiAllReduce
-            ar = XgmiAllReduce(cap, self.device, self.rank, self.world_size,
-                               n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")))
-            ok = self._verify_xgmi(ar, numel)                   # keeps the 1 s poll bound: see _agree below
-        except Exception as e:                                  # noqa: BLE001 - any failure means "use RCCL"
-            ok, why = False, repr(e)
-        # the verdict of the verification is agreed on BEFORE anything else is launched on the direct path: on a broken
-        # IPC / xGMI path every further launch would burn its poll bound in three timed-out barriers
-        ok = self._agree(ok)
-        if ok:
+        # the communication buffer lives in ordinary (cached) device memory; if THAT form does not reproduce the process
+        # group's sums on this node (every other failure - no IPC, no peer access - is independent of the memory kind),
+        # the same protocol is tried once more on fine-grained memory, which needs no cache maintenance to be coherent
+        kinds = [k for k in os.environ.get("DRL_XGMI_MEM", "coarse,fine").split(",") if k]
+        ar, why, ok = None, "", False
+        for kind in kinds:
+            ar, why, ok, verified = None, "", False, False
             try:
-                ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
-                # both paths are correct here: keep the direct kernel unless the process group's all-reduce is clearly
-                # faster on THIS node (every rank times both - collective calls - and the slowest rank's numbers decide)
-                t_x, t_pg = self._time_all_reduces(ar, numel)
-                self.all_reduce_us = {"direct_xgmi": round(t_x, 1), "process_group": round(t_pg, 1)}
-                if mode != "1" and t_x > 1.25 * t_pg:
-                    ok, why = False, "slower than the process group here: %.0f vs %.0f us" % (t_x, t_pg)
-            except Exception as e:                              # noqa: BLE001
+                import socket
+                hosts = [None] * self.world_size
+                td.all_gather_object(hosts, socket.gethostname(), group=self.group)
+                if len(set(hosts)) != 1:
+                    raise RuntimeError("ranks on different hosts")
+                from .xgmi import XgmiAllReduce
+                ar = XgmiAllReduce(cap, self.device, self.rank, self.world_size, group=self.group,
+                                   n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")), mem_kind=kind)
+                verified = True
+                ok = self._verify_xgmi(ar, numel)               # keeps the 1 s poll bound: see _agree below
+                if not ok:
+                    why = "sums differ from the process group's (%s memory)" % kind
+            except Exception as e:                              # noqa: BLE001 - any failure means "use RCCL"
                 ok, why = False, repr(e)
+            # the verdict of the verification is agreed on BEFORE anything else is launched on the direct path: on a
+            # broken IPC / xGMI path every further launch would burn its poll bound in three timed-out barriers
             ok = self._agree(ok)
-        if not ok:
+            if ok:
+                try:
+                    ar.set_timeout(float(os.environ.get("DRL_XGMI_TIMEOUT_S", "60")))
+                    # both paths are correct here: keep the direct kernel unless the process group's all-reduce is
+                    # clearly faster on THIS node (every rank times both - collective calls - and the slowest rank's
+                    # numbers decide); the direct kernel is timed at several grid sizes and keeps the best
+                    t_x, t_pg = self._time_all_reduces(ar, numel)
+                    self.all_reduce_us = {"direct_xgmi": round(t_x, 1), "process_group": round(t_pg, 1),
+                                          "direct_xgmi_by_blocks": self._xgmi_sweep, "blocks": ar.n_blocks, "memory": kind}
+                    if mode != "1" and t_x > 1.25 * t_pg:
+                        ok, why = False, "slower than the process group here: %.0f vs %.0f us" % (t_x, t_pg)
+                except Exception as e:                          # noqa: BLE001
+                    ok, why = False, repr(e)
+                ok = self._agree(ok)
+                if ok:
+                    break
             if ar is not None:
                 try:
                     ar.close()
                 except Exception:                               # noqa: BLE001
                     pass
+                ar = None
+            self.fallbacks.append("xgmi(%s memory) rejected: %s" % (kind, why or "verification failed on some rank"))
+            if not self._agree(verified and "sums differ" in why):
+                break                                           # not a coherence problem: another memory kind changes nothing
+        if not ok:
             if mode == "1":
                 raise RuntimeError("DRL_XGMI_AR=1 but the direct xGMI all-reduce is not usable: %s" % (why or "mismatch"))
             self.fallbacks.append("xgmi->process_group: %s" % (why or "verification failed on some rank"))
@@ -152,27 +180,36 @@ class Dist:
         """Same verdict on every rank (MIN); a rank that cannot even take the collective votes no."""
         try:
             v = torch.tensor([1.0 if ok else 0.0], device=self.device)
-            td.all_reduce(v, op=td.ReduceOp.MIN)
+            td.all_reduce(v, op=td.ReduceOp.MIN, group=self.group)
             return float(v.item()) > 0.5
         except Exception:                                       # noqa: BLE001
             return False
 
-    def _verify_xgmi(self, ar, numel: int) -> bool:
-        """The kernel against RCCL on rank-dependent random data: whole buffer, an engine-like split on two channels. Any
-        mismatch, launch error or timed-out poll rejects the path. The loop contains collectives of the process group:
+    def _verify_xgmi(self, ar, numel: int, rounds: Optional[int] = None) -> bool:
+        """The kernel against the process group on rank-dependent data that CHANGES between collectives (every round the
+        buffer is rewritten by kernels, as the backward pass does, so a peer that kept stale lines of it - or a flag that
+        overtook the data - shows up as a wrong sum): whole buffer, an engine-like split on two channels, alternating.
+        Any mismatch, launch error or timed-out poll rejects the path. The loop contains collectives of the process group:
         every rank takes all of them, whatever happens to its own kernel launches (a local failure is only recorded)."""
+        rounds = int(os.environ.get("DRL_XGMI_VERIFY_ROUNDS", "50")) if rounds is None else rounds
         g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
         cut = (numel // 41) // 64 * 64
         ar.set_timeout(1.0)                                     # a broken path must fail fast, not look like a hang
+        noise = torch.empty(numel, device=self.device).normal_(generator=g)
+        want = torch.empty_like(ar.flat)
         good = True
-        for k in range(3):
+        for k in range(rounds):
             ar.flat.zero_()
-            ar.flat[:numel].normal_(generator=g)
-            want = ar.flat.clone()
-            td.all_reduce(want, op=td.ReduceOp.SUM)
+            # new values in every element, every round, cheap: a rolled copy of the rank's noise scaled by the round
+            sh = (k * 7919 + 13 * self.rank) % max(1, numel)
+            ar.flat[:numel - sh].copy_(noise[sh:])
+            ar.flat[numel - sh:numel].copy_(noise[:sh])
+            ar.flat[:numel].mul_(1.0 + 0.125 * (k % 5))
+            want.copy_(ar.flat)
+            td.all_reduce(want, op=td.ReduceOp.SUM, group=self.group)
             torch.cuda.synchronize(self.device)
             try:
-                if k == 0:
+                if k % 2 == 0:
                     ar.all_reduce(ar.flat[:numel], channel=0)
                 else:
                     ar.all_reduce(ar.flat[cut:numel], channel=0)
@@ -181,14 +218,18 @@ class Dist:
                 good = good and ar.error() == 0 and bool(torch.allclose(ar.flat, want, rtol=1e-4, atol=1e-4))
             except Exception:                                   # noqa: BLE001
                 good = False
+            if not self._agree(good):                           # stop early, TOGETHER (the body has a collective)
+                return False
         return good                                             # the caller restores the production poll bound
 
     def _time_all_reduces(self, ar, numel: int, iters: int = 20) -> tuple:
-        """us per all-reduce of the gradient buffer: (direct kernel, process group), max over ranks."""
+        """us per all-reduce of the gradient buffer: (direct kernel at its best grid size, process group), max over
+        ranks. The direct kernel is timed with 16 / 32 / 64 workgroups (``DRL_XGMI_SWEEP``; a set ``DRL_XGMI_BLOCKS`` pins
+        it) and left at the fastest - identical on every rank, because the decision is taken on all-reduced times."""
         import time
         tmp = torch.zeros(numel, device=self.device)
-        out = []
-        for fn in (lambda: ar.all_reduce(ar.flat[:numel], channel=2), lambda: td.all_reduce(tmp, op=td.ReduceOp.SUM)):
+
+        def clock(fn):
             for _ in range(3):
                 fn()
                 torch.cuda.synchronize(self.device)
@@ -196,10 +237,24 @@ class Dist:
             for _ in range(iters):                              # one at a time (the same for both paths): gloo's CUDA path,
                 fn()                                            # used for rehearsals, stalls on back-to-back collectives
                 torch.cuda.synchronize(self.device)
-            out.append((time.perf_counter() - t0) / iters * 1e6)
+            return (time.perf_counter() - t0) / iters * 1e6
+
+        if os.environ.get("DRL_XGMI_BLOCKS"):
+            cands = [ar.n_blocks]
+        else:
+            cands = [int(x) for x in os.environ.get("DRL_XGMI_SWEEP", "16,32,64").split(",") if x]
+        out = []
+        for nb in cands:
+            ar.set_blocks(nb)
+            out.append(clock(lambda: ar.all_reduce(ar.flat[:numel], channel=2)))
+        out.append(clock(lambda: td.all_reduce(tmp, op=td.ReduceOp.SUM, group=self.group)))
         v = torch.tensor(out, dtype=torch.float64, device=self.device)
-        td.all_reduce(v, op=td.ReduceOp.MAX)
-        return float(v[0]), float(v[1])
+        td.all_reduce(v, op=td.ReduceOp.MAX, group=self.group)
+        ts = [float(x) for x in v.tolist()]
+        best = min(range(len(cands)), key=lambda i: ts[i])
+        ar.set_blocks(cands[best])
+        self._xgmi_sweep = {str(nb): round(t, 1) for nb, t in zip(cands, ts)}
+        return ts[best], ts[-1]
 
     def check_health(self) -> None:
         """Raises if a poll of the direct all-reduce timed out since the last call (a peer did not arrive). Synchronises."""
@@ -216,7 +271,7 @@ class Dist:
         if self.xgmi is not None and self.xgmi.owns(flat):
             self.xgmi.all_reduce(flat, channel=0)
             return
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        td.all_reduce(flat, op=td.ReduceOp.SUM, group=self.group)
 
     def all_reduce_async(self, flat: torch.Tensor, channel: int = 0):
         """SUM over ranks, in place, asynchronous: the collective runs on a side stream (RCCL's own, or ours for the
@@ -230,7 +285,7 @@ class Dist:
             with torch.cuda.stream(side):
                 self.xgmi.all_reduce(flat, channel=channel)
             return _StreamWork(side)
-        return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True)
+        return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True, group=self.group)
 
     def all_reduce_grads(self, module: torch.nn.Module) -> None:
         """PyTorch-learner path: flatten → one all-reduce → average → scatter back."""
@@ -238,7 +293,7 @@ class Dist:
             return
         grads = [p.grad for p in module.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        td.all_reduce(flat, op=td.ReduceOp.SUM, group=self.group)
         flat.div_(self.world_size)
         o = 0
         for g in grads:
@@ -286,7 +341,7 @@ class Dist:
         ok = 1.0
         try:
             x = torch.ones(4096, device=self.device)
-            td.all_reduce(x)                                   # communicator warm-up outside capture
+            td.all_reduce(x, group=self.group)                                   # communicator warm-up outside capture
             self.quiesce()
             buf = torch.ones(4096, device=self.device)
             side = torch.cuda.Stream(self.device)
@@ -294,7 +349,7 @@ class Dist:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    w = td.all_reduce(buf, op=td.ReduceOp.SUM, async_op=True)
+                    w = td.all_reduce(buf, op=td.ReduceOp.SUM, async_op=True, group=self.group)
                     w.wait()
                     buf.mul_(1.0 / self.world_size)            # back to ones: replays are idempotent
             torch.cuda.current_stream().wait_stream(side)
@@ -307,22 +362,22 @@ class Dist:
             ok = 0.0
         try:                                                   # agree across ranks (eager collective)
             v = torch.tensor([ok], device=self.device)
-            td.all_reduce(v, op=td.ReduceOp.MIN)
+            td.all_reduce(v, op=td.ReduceOp.MIN, group=self.group)
             ok = float(v.item())
         except Exception:
             ok = 0.0
         return ok > 0.5
 
     def broadcast_flat(self, flat: torch.Tensor, src: int = 0) -> None:
-        if self.enabled:
-            td.broadcast(flat, src=src)
+        if self.enabled:       # ``src`` is a rank of THIS object's group
+            td.broadcast(flat, src=src if self.group is None else td.get_global_rank(self.group, src), group=self.group)
 
     def shard_scalars(self, total_prio: float, n_items: int) -> tuple:
         """→ (Σp over all shards, N over all shards)."""
         if not self.enabled:
             return total_prio, n_items
         t = torch.tensor([total_prio, float(n_items)], dtype=torch.float64, device=self.device)
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
         return float(t[0]), int(t[1])
 
     def mean_count(self, n_local: torch.Tensor, out: torch.Tensor, tmp: torch.Tensor) -> None:
@@ -337,11 +392,11 @@ class Dist:
         if self.backend != "nccl" and n_local.is_cuda:
             torch.cuda.synchronize(self.device)
             t = n_local.cpu()
-            td.all_reduce(t, op=td.ReduceOp.SUM)
+            td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
             out.copy_((t + self.world_size // 2) // self.world_size)
             return
         tmp.copy_(n_local)
-        td.all_reduce(tmp, op=td.ReduceOp.SUM)
+        td.all_reduce(tmp, op=td.ReduceOp.SUM, group=self.group)
         tmp.add_(self.world_size // 2)
         out.copy_(torch.div(tmp, self.world_size, rounding_mode="floor"))
 
@@ -349,19 +404,30 @@ class Dist:
         if not self.enabled:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=self.device)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
+        td.all_reduce(t, op=td.ReduceOp.MAX, group=self.group)
         return float(t[0])
+
+    def any_true(self, flag: bool) -> bool:
+        """True on every rank iff ``flag`` is set on at least one (a stop request must take all data-parallel ranks out
+        of their loops at the SAME step: the step contains collectives). Travels over gloo on a host tensor when the
+        group has a CPU backend - no device synchronisation - else as a device scalar."""
+        if not self.enabled:
+            return bool(flag)
+        on_cpu = "gloo" in str(self.backend)
+        t = torch.tensor([1.0 if flag else 0.0], device="cpu" if on_cpu else self.device)
+        td.all_reduce(t, op=td.ReduceOp.MAX, group=self.group)
+        return float(t.item()) > 0.5
 
     def barrier(self) -> None:
         if self.enabled:
             if self.backend == "nccl":
-                td.barrier(device_ids=[self.device.index])
+                td.barrier(group=self.group, device_ids=[self.device.index])
             else:
-                td.barrier()
+                td.barrier(group=self.group)
 
     def close(self) -> None:
         if self.xgmi is not None:
             self.xgmi.close()
             self.xgmi = None
-        if self.enabled and td.is_initialized():
+        if self.enabled and self._owns_world and td.is_initialized():
             td.destroy_process_group()

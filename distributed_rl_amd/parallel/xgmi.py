@@ -24,6 +24,7 @@ from .. import native
 
 N_CHANNELS = 4
 MAX_WORLD = 8
+MEM_KINDS = {"coarse": 0, "fine": 1, "uncached": 2}      # where the communication buffer lives (xgmi_ar.hip drl_xar_create2)
 
 
 class _DevMem:
@@ -37,7 +38,7 @@ class _DevMem:
 
 class XgmiAllReduce:
     def __init__(self, numel: int, device: torch.device, rank: int, world: int, group=None, n_blocks: int = 32,
-                 timeout_s: float = 20.0):
+                 timeout_s: float = 20.0, mem_kind: str = "coarse"):
         if world > MAX_WORLD:
             raise ValueError("xGMI all-reduce: at most %d ranks (one node)" % MAX_WORLD)
         self.lib = native.hip()
@@ -45,6 +46,7 @@ class XgmiAllReduce:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.rank, self.world, self.device = rank, world, device
+        self.mem_kind, self.n_blocks = mem_kind, int(n_blocks)
         self.cap = (numel + 63) // 64 * 64
         self._ctx = ctypes.c_void_p()
         self.flat, self._base = None, 0
@@ -56,7 +58,8 @@ class XgmiAllReduce:
         vis = os.environ.get("HIP_VISIBLE_DEVICES", "") + "|" + os.environ.get("ROCR_VISIBLE_DEVICES", "")
         with torch.cuda.device(self.device):
             try:
-                self._ck(self.lib.drl_xar_create(rank, world, self.cap, n_blocks, timeout_s, ctypes.byref(self._ctx)), "create")
+                self._ck(self.lib.drl_xar_create2(rank, world, self.cap, n_blocks, timeout_s, MEM_KINDS[mem_kind],
+                                                      ctypes.byref(self._ctx)), "create")
                 self._ck(self.lib.drl_xar_handles(self._ctx, mine), "handles")
             except Exception as e:                                 # noqa: BLE001
                 ok, why = False, repr(e)
@@ -109,6 +112,12 @@ class XgmiAllReduce:
         n = min((t.numel() + 3) // 4 * 4, self.cap - off)       # the padding is zero on every rank
         self._ck(self.lib.drl_xar_all_reduce(self._ctx, off, n, channel, torch.cuda.current_stream(self.device).cuda_stream),
                  "launch")
+
+    def set_blocks(self, n_blocks: int) -> None:
+        """Workgroups per collective from the next launch on (1..64). Every rank must switch at the same point of its
+        launch sequence: block b pairs up with block b of every peer."""
+        self._ck(self.lib.drl_xar_set_blocks(self._ctx, int(n_blocks)), "set_blocks")
+        self.n_blocks = int(n_blocks)
 
     def set_timeout(self, seconds: float) -> None:
         """Bound of every flag poll inside the kernel (launches issued after this call)."""

@@ -72,13 +72,16 @@ def main() -> int:
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--bench", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=32)
+    ap.add_argument("--soak", type=int, default=0, help="N back-to-back collectives on data that changes every step, each "
+                                                       "one checked (device-side checksum against the host's sum over ranks)")
+    ap.add_argument("--mem", default="coarse", choices=["coarse", "fine", "uncached"])
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     td.init_process_group("gloo", rank=rank, world_size=world)
     from distributed_rl_amd.parallel.xgmi import XgmiAllReduce
-    ar = XgmiAllReduce(a.numel, dev, rank, world, n_blocks=a.blocks)
+    ar = XgmiAllReduce(a.numel, dev, rank, world, n_blocks=a.blocks, mem_kind=a.mem)
     res = {"rank": rank, "world": world, "device": str(dev), "numel": a.numel, "checks": 0, "max_err": 0.0}
     ok = True
     g = torch.Generator().manual_seed(100 + rank)
@@ -124,6 +127,49 @@ def main() -> int:
     tot = float(sum(range(1, world + 1)))
     ok = ok and bool((ar.flat[:a.numel] == tot).all())
     res["graph_ok"] = bool((ar.flat[:a.numel] == tot).all())
+    if a.soak:
+        # A long run on changing data without host barriers between the collectives: step k's input is written by kernels
+        # (like the backward pass) right before the collective, alternating grid sizes and channels; every rank keeps a
+        # device-side record (sum, sum of squares, three probes) of each result, compared afterwards with what the host
+        # computes from all ranks' inputs. A peer that read stale lines, or a flag that overtook its data, shows up here.
+        base = torch.randn(a.numel, generator=g).to(dev)
+        rec = torch.zeros(a.soak, 5, dtype=torch.float64, device=dev)
+        probes = torch.tensor([1, a.numel // 2 + 3, a.numel - 2], device=dev)
+        td.barrier()
+        with torch.cuda.stream(s):
+            for k in range(a.soak):
+                if k % 50 == 0:
+                    ar.set_blocks((16, 32, 64)[(k // 50) % 3])     # every rank switches at the same collective
+                sh = (k * 9973 + 1) % a.numel
+                ar.flat[:a.numel - sh].copy_(base[sh:])
+                ar.flat[a.numel - sh:a.numel].copy_(base[:sh])
+                ar.flat[:a.numel].mul_(1.0 + 0.0625 * ((k + rank) % 7))
+                if k % 3 == 2:
+                    ar.all_reduce(ar.flat[cut:a.numel], channel=0)
+                    ar.all_reduce(ar.flat[:cut], channel=1)
+                else:
+                    ar.all_reduce(ar.flat[:a.numel], channel=k % 3)
+                v = ar.flat[:a.numel].double()
+                rec[k, 0], rec[k, 1] = v.sum(), (v * v).sum()
+                rec[k, 2:] = v[probes]
+            torch.cuda.synchronize()
+        # expectation on the host: every rank's base travels once over gloo
+        bases = [torch.zeros(a.numel) for _ in range(world)]
+        td.all_gather(bases, base.cpu())
+        worst = 0.0
+        for k in range(a.soak):
+            sh = (k * 9973 + 1) % a.numel
+            tot = torch.zeros(a.numel, dtype=torch.float64)
+            for r in range(world):
+                tot += torch.roll(bases[r], -sh).double() * (1.0 + 0.0625 * ((k + r) % 7))
+            want = torch.tensor([float(tot.sum()), float((tot * tot).sum()), *[float(tot[i]) for i in probes.tolist()]],
+                                dtype=torch.float64)
+            got = rec[k].cpu()
+            err = float(((got - want).abs() / (want.abs() + 1.0)).max())
+            worst = max(worst, err)
+        res["soak_steps"], res["soak_worst_rel_err"] = a.soak, worst
+        ok = ok and worst < 1e-4
+        ar.set_blocks(a.blocks)
     if a.bench:
         td.barrier()
         t0 = time.perf_counter()

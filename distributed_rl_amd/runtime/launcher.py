@@ -28,7 +28,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def build_commands(conf, n_actors: int, server: str, run_id: str, extra_learner: List[str], extra_actor: List[str],
-                   python: str = sys.executable) -> Dict[str, List[str]]:
+                   python: str = sys.executable, plan=None) -> Dict[str, List[str]]:
+    """One command line per child. Learner ranks are started here, one process each (``learner``, ``learner_r1``, ...), so
+    the supervisor sees every rank; devices, shards and parameter lanes come from ``plan`` (runtime/placement.py)."""
+    from .placement import make_plan
+    plan = plan if plan is not None else make_plan(conf, n_actors)
     redis_server = conf.redis_server or server or "localhost"       # run.sh:7-13
     visdom_server = conf.visdom_server or (server if conf.visdom else "")
     cmds: Dict[str, List[str]] = {}
@@ -37,42 +41,57 @@ def build_commands(conf, n_actors: int, server: str, run_id: str, extra_learner:
         common += ["-v", visdom_server]
     if conf.visdom:
         cmds["visdom"] = [python, "-m", "visdom.server", "-logging_level", "WARNING"]       # run.sh:20-24
-    n_ranks = max(1, int(conf.learner_gpus))
+    n_ranks = plan.n_learners
+    lane = ["--param-channel", "collective", "--param-backend", conf.param_backend]
     if conf.learner:
-        if n_ranks > 1:      # data-parallel learners: one rank per GPU, rendezvous on loopback
-            c = [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
-                 "127.0.0.1", "--master-port", str(29400 + (abs(hash(run_id)) % 500)),
-                 os.path.join(ROOT, "learner_node.py")] + common
-        else:
-            c = [python, os.path.join(ROOT, "learner_node.py")] + common
-        if conf.actor_device:
-            c += ["-d", conf.actor_device]                                                   # run.sh:27-33
-        cmds["learner"] = c + extra_learner
-    if conf.param_channel == "collective":
-        # learner -> actors parameter sync by broadcast (RCCL between GPUs, gloo on CPU) instead of the shm register:
-        # learner = rank 0, actor i = rank i of one process group (environment set per child in main())
-        if n_ranks > 1:
-            raise SystemExit("param_channel=collective needs learner_gpus=1 (the data-parallel learners own the default group)")
-        common = common + ["--param-channel", "collective", "--param-backend", conf.param_backend]
-        if "learner" in cmds:
-            cmds["learner"] = cmds["learner"] + ["--param-channel", "collective", "--param-backend", conf.param_backend]
+        for k, dev in enumerate(plan.learner_devices):
+            c = [python, os.path.join(ROOT, "learner_node.py")] + common + ["--device", dev]
+            if conf.actor_device:
+                c += ["-d", conf.actor_device]                                               # run.sh:27-33
+            if any(r[0] == k for r in plan.lanes):
+                on_register = sum(1 for a in plan.actors if a.shard == k and a.channel == "register")
+                c += lane + ["--register-actors", str(on_register if conf.actor else -1)]
+            cmds["learner" if k == 0 else "learner_r%d" % k] = c + extra_learner
     if conf.actor:
-        for i in range(1, n_actors + 1):                                                     # run.sh:36-42
-            cmds["actor_%d" % i] = [python, os.path.join(ROOT, "actor_node.py"), "-n", str(i), "-t", str(n_actors)] + \
-                common + ["--num-envs", str(conf.num_envs), "--learner-ranks", str(n_ranks)] + extra_actor
+        for a in plan.actors:                                                                # run.sh:36-42
+            c = [python, os.path.join(ROOT, "actor_node.py"), "-n", str(a.no), "-t", str(n_actors)] + common + \
+                ["--num-envs", str(conf.num_envs), "--learner-ranks", str(n_ranks), "--device", a.device]
+            if a.channel == "collective":
+                c += lane
+            cmds["actor_%d" % a.no] = c + extra_actor
     return cmds
 
 
+def child_envs(plan, names, port: int) -> Dict[str, Dict[str, str]]:
+    """Extra environment per child: world membership (learner ranks, lane actors) and the data-parallel identity."""
+    from .placement import child_env
+    out: Dict[str, Dict[str, str]] = {n: {} for n in names}
+    L = plan.n_learners
+    for k in range(L):
+        name = "learner" if k == 0 else "learner_r%d" % k
+        if name in out:
+            out[name].update(DRL_LEARNER_RANK=str(k), DRL_LEARNER_RANKS=str(L))
+            if plan.world_size:
+                out[name].update(child_env(plan, "127.0.0.1", port, k))
+    for a in plan.actors:
+        name = "actor_%d" % a.no
+        if name in out and a.channel == "collective":
+            out[name].update(child_env(plan, "127.0.0.1", port, a.world_rank))
+    return out
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _free_beats(hb_table, name: str, pid: int) -> None:
-    """Heartbeat rows of a reaped child: its own pid, and for the learner (whose ranks may be grandchildren under
-    torch.distributed.run) every row of role learner."""
+    """Heartbeat rows of a reaped child (every learner rank is a child of its own)."""
     if hb_table is None:
         return
     hb_table.free_pid(pid)
-    if name == "learner":
-        for row in hb_table.snapshot():
-            if row["role"] == "learner":
-                hb_table.free_pid(row["pid"])
 
 
 def main(argv=None) -> int:
@@ -89,16 +108,23 @@ def main(argv=None) -> int:
     ap.add_argument("--actor-args", type=str, default="", help="extra flags for actor_node.py (one string)")
     ap.add_argument("--timeout", type=float, default=0.0, help="stop everything after this many seconds (0 = never)")
     ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--gpus", type=int, default=-1, help="GPUs to place processes on (-1 = all visible; 0 = CPU only)")
     args = ap.parse_args(argv)
 
     conf = parse_conf(args.conf)
-    if conf.param_channel == "collective" and args.restart_actors:
-        raise SystemExit("param_channel=collective and --restart-actors exclude each other (a process group cannot re-admit a rank)")
+    from .placement import make_plan
+    plan = make_plan(conf, args.num_actors if conf.actor else 0, args.gpus if args.gpus >= 0 else None)
+    if plan.lanes and not conf.actor:
+        raise SystemExit("param_channel=collective needs the lane actors in the same launcher run (one process-group world)")
+    restartable = {"actor_%d" % a.no for a in plan.actors if a.channel == "register"}    # world members cannot re-join
     run_id = args.run_id or conf.run_dir or uuid.uuid4().hex[:8]
-    cmds = build_commands(conf, args.num_actors, args.server, run_id, args.learner_args.split(), args.actor_args.split())
+    cmds = build_commands(conf, args.num_actors, args.server, run_id, args.learner_args.split(), args.actor_args.split(),
+                          plan=plan)
     print("redis server:", conf.redis_server or args.server)
     print("visdom server:", conf.visdom_server or args.server)
     print("transport:", conf.transport, "run-id:", run_id)
+    for line in plan.describe():
+        print("placement:", line)
     if args.dry_run:
         for k, c in cmds.items():
             print(k, " ".join(c))
@@ -112,14 +138,10 @@ def main(argv=None) -> int:
     procs: Dict[str, subprocess.Popen] = {}
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONUNBUFFERED="1")
 
-    pc_port = str(29900 + (abs(hash(run_id)) % 500))
+    extra_env = child_envs(plan, list(cmds), _free_port())
 
     def spawn(name):
-        e = env
-        if conf.param_channel == "collective" and name != "visdom":
-            rank = 0 if name == "learner" else int(name.split("_")[1])
-            e = dict(env, DRL_PC_RANK=str(rank), DRL_PC_WORLD=str(1 + args.num_actors), DRL_PC_ADDR="127.0.0.1", DRL_PC_PORT=pc_port)
-        procs[name] = subprocess.Popen(cmds[name], env=e, cwd=ROOT)
+        procs[name] = subprocess.Popen(cmds[name], env=dict(env, **extra_env.get(name, {})), cwd=ROOT)
 
     def teardown():
         for p in procs.values():
@@ -146,9 +168,11 @@ def main(argv=None) -> int:
         if "visdom" in cmds:
             spawn("visdom")
             time.sleep(2)
-        if "learner" in cmds:
-            spawn("learner")
-            time.sleep(1.0)       # let the learner create the shm segments actors attach to
+        learners = [n for n in cmds if n == "learner" or n.startswith("learner_r")]
+        for name in learners:
+            spawn(name)
+        if learners:
+            time.sleep(1.0)       # let the learners create the shm segments actors attach to
         for name in cmds:
             if name.startswith("actor_"):
                 spawn(name)
@@ -163,13 +187,25 @@ def main(argv=None) -> int:
                 if code is None:
                     continue
                 _free_beats(hb_table, name, p.pid)       # a killed child could not unregister its heartbeat slot
-                if name.startswith("actor_") and args.restart_actors and not stop["flag"]:
+                if name in restartable and args.restart_actors and not stop["flag"]:
                     print("[launcher] %s exited with %s, restarting" % (name, code), flush=True)
                     spawn(name)
                     restarts[name] = restarts.get(name, 0) + 1
                     continue
                 print("[launcher] %s exited with %s, shutting down" % (name, code), flush=True)     # wait -n semantics
-                rc = code if name == "learner" or code != 0 else rc
+                rc = code if name.startswith("learner") or code != 0 else rc
+                if name.startswith("learner") and code == 0:
+                    # data-parallel learners finish together (same step count): give the other ranks a moment to return
+                    # by themselves - and to write what they write at the end - before everything is torn down
+                    t_grace = time.time() + 20.0
+                    for other, q in procs.items():
+                        if other != name and other.startswith("learner"):
+                            try:
+                                c2 = q.wait(max(0.1, t_grace - time.time()))
+                                print("[launcher] %s exited with %s" % (other, c2), flush=True)
+                                rc = rc or c2
+                            except subprocess.TimeoutExpired:
+                                print("[launcher] %s still running after rank exit, terminating" % other, flush=True)
                 stop["flag"] = True
                 break
             if hb_table is not None and time.time() - last_watch > args.watch_period:
@@ -179,7 +215,8 @@ def main(argv=None) -> int:
                         continue
                     # only processes THIS launcher started are ever signalled: the row is mapped back to a child of the
                     # procs table by role and ident (a stale row's pid may belong to anybody by now)
-                    name = "learner" if row["role"] == "learner" else "actor_%d" % row["ident"] if row["role"] == "actor" else ""
+                    name = ("learner" if row["ident"] == 0 else "learner_r%d" % row["ident"]) if row["role"] == "learner" else \
+                        "actor_%d" % row["ident"] if row["role"] == "actor" else ""
                     child = procs.get(name)
                     print("[launcher] %s %d (pid %d) silent for %.0f s" % (row["role"], row["ident"], row["pid"], row["age_s"]),
                           flush=True)

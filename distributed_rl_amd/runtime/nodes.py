@@ -32,10 +32,12 @@ def _common(parser):
     parser.add_argument('--quiet', action='store_true')
     parser.add_argument('--device', type=str, default='', help="'' = cuda if available else cpu.")
     parser.add_argument('--param-channel', type=str, default='', choices=['', 'collective'],
-                        help="collective = parameters reach the actors by torch.distributed broadcast (RCCL / gloo) instead of "
-                             "the transport's register; rank / world / rendezvous come from DRL_PC_RANK / _WORLD / _ADDR / _PORT.")
+                        help="collective = this process is a member of the launcher's torch.distributed world "
+                             "(DRL_WORLD_PLAN / _RANK / _ADDR / _PORT, runtime/placement.py): actors receive parameters by "
+                             "broadcast over their lane (RCCL between GPUs, gloo on CPU) instead of the transport's register.")
     parser.add_argument('--param-backend', type=str, default='gloo', choices=['gloo', 'nccl'],
-                        help="backend of the collective parameter channel (nccl = RCCL: every process on its own GPU).")
+                        help="what the lanes carry: nccl = device tensors over RCCL (every lane member on its own GPU), "
+                             "gloo = host tensors.")
 
 
 def shard_run_id(run_id: str, rank: int, world: int) -> str:
@@ -51,22 +53,32 @@ def _flat_numel(algorithm: str, n_action: int) -> int:
     return ParamPack(lay, 'cpu').flat.numel()
 
 
-def _collective_params(args, numel: int, device: torch.device):
-    """Join the parameter process group (learner = rank 0, actor i = rank i) and return the broadcast channel."""
-    import datetime
-    import torch.distributed as td
+def _lane_device(world, device: torch.device) -> torch.device:
+    """Where a lane's tensors live: the member's GPU when the lanes carry device tensors (RCCL), else the host."""
+    return device if (world.param_backend == 'nccl' and device.type == 'cuda') else torch.device('cpu')
+
+
+def _actor_lane(world, numel: int, device: torch.device):
+    """Actor side of the collective parameter channel: the receiver of the ONE lane this world rank belongs to."""
     from ..transport.collective_params import CollectiveParams
-    rank, world = int(os.environ["DRL_PC_RANK"]), int(os.environ["DRL_PC_WORLD"])
-    addr, port = os.environ.get("DRL_PC_ADDR", "127.0.0.1"), os.environ.get("DRL_PC_PORT", "29900")
-    if args.param_backend == 'nccl':
-        torch.cuda.set_device(device)
-    td.init_process_group(args.param_backend, init_method="tcp://%s:%s" % (addr, port), rank=rank, world_size=world,
-                          timeout=datetime.timedelta(seconds=float(os.environ.get("DRL_CONNECT_TIMEOUT", "120"))))
-    dev = device if args.param_backend == 'nccl' else torch.device('cpu')
-    return CollectiveParams(numel, src_rank=0, group=None, device=dev)
+    mine = world.my_lanes()
+    if len(mine) != 1:
+        raise SystemExit("world rank %d belongs to %d parameter lanes (expected exactly one)" % (world.rank, len(mine)))
+    lane = mine[0]
+    return CollectiveParams(numel, src_rank=world.lanes[lane][0], group=world.lane_groups[lane], device=_lane_device(world, device))
+
+
+def _learner_fanout(world, register, numel: int, device: torch.device, keep_register: bool):
+    """Learner side: the shard's register (co-located / CPU actors) + every lane that starts at this learner rank."""
+    from ..transport.collective_params import CollectiveParams, FanoutParams
+    lanes = [CollectiveParams(numel, src_rank=world.rank, group=world.lane_groups[i], device=_lane_device(world, device))
+             for i in world.my_lanes()]
+    return FanoutParams(register if keep_register else None, lanes)
 
 
 def _device(name: str) -> torch.device:
+    """'' = this process was started by hand: cuda (the current device) if there is one. The launcher always names the
+    device (runtime/placement.py), so actors of a multi-GPU node never pile up on GPU 0."""
     if name:
         return torch.device(name)
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -114,9 +126,16 @@ def actor_main(argv=None) -> int:
             if _time.time() > t_end:
                 raise
             _time.sleep(0.25)
+    world = None
     if args.param_channel == 'collective':
+        from ..parallel.world import join_world
+        world = join_world(device)
+        if world is None:
+            raise SystemExit("--param-channel collective without a world plan (DRL_WORLD_PLAN): start through run.sh / the launcher")
         par.close()
-        par = _collective_params(args, _flat_numel(args.algorithm, env.n_action), device)
+        par = _actor_lane(world, _flat_numel(args.algorithm, env.n_action), device)
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
     hb = _heartbeat(args, "actor", args.no)
     if args.algorithm == 'ape_x':
         engine = None
@@ -167,6 +186,9 @@ def learner_main(argv=None) -> int:
     parser.add_argument('--target-update', type=int, default=None)
     parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'torch', 'hip'],
                         help='torch = ATen learner; hip = graph-captured gfx950 engine (needs a GPU).')
+    parser.add_argument('--register-actors', type=int, default=-1,
+                        help="number of this shard's actors that read the parameter register (-1 = unknown: keep publishing "
+                             "to it); 0 lets a learner whose actors are all on broadcast lanes skip the host copy.")
     parser.add_argument('--ring-slots', type=int, default=64)
     parser.add_argument('--ring-slot-mb', type=int, default=8)
     _common(parser)
@@ -175,22 +197,37 @@ def learner_main(argv=None) -> int:
     cfg = make_config(args.algorithm, batch_size=args.batch_size, start_memory_size=args.start_memory_size,
                       save_timing=args.save_timing, target_update=args.target_update)
     n_action = envs.n_action_of(args.env)             # the reference builds a whole env just for this (learner_node.py:20)
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and device.type == "cuda":
-        lr_ = int(os.environ.get("LOCAL_RANK", "0"))
-        if os.environ.get("DRL_SHARE_GPU") == "1":         # rehearsal: more ranks than GPUs (see parallel/dist.py)
-            lr_ %= torch.cuda.device_count()
-        device = torch.device("cuda", lr_)
+    # data-parallel identity: from the launcher's world plan (one process per rank, started by runtime/launcher.py), or
+    # from torch.distributed.run's RANK / WORLD_SIZE when the ranks were started that way
+    from ..parallel.world import join_world, world_from_env
+    spec = world_from_env()
+    if spec is not None:
+        rank, world = int(os.environ["DRL_WORLD_RANK"]), int(spec["learners"])
+    else:
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and device.type == "cuda" and not args.device:
+            lr_ = int(os.environ.get("LOCAL_RANK", "0"))
+            if os.environ.get("DRL_SHARE_GPU") == "1":         # rehearsal: more ranks than GPUs (see parallel/dist.py)
+                lr_ %= torch.cuda.device_count()
+            device = torch.device("cuda", lr_)
     metrics = make_metrics("learner" if rank == 0 else "learner_r%d" % rank, args.visdomserver, args.log_dir,
                            args.quiet or rank > 0)
     exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=True, host=args.redisserver,
                        n_slots=args.ring_slots, slot_bytes=args.ring_slot_mb << 20)
     register = None
-    if args.param_channel == 'collective':
+    dist = None
+    pg_world = join_world(device) if spec is not None else None
+    if pg_world is not None:
+        from ..parallel.dist import Dist
         if world > 1:
-            raise SystemExit("--param-channel collective needs a single learner rank")
-        register = par               # stays open (unused): actors attach to both segments of the transport before they switch
-        par = _collective_params(args, _flat_numel(args.algorithm, n_action), device)
+            dist = Dist(device=device, group=pg_world.learner_group)
+        if pg_world.my_lanes():
+            register = par           # stays open either way: actors attach to both segments of the transport first
+            par = _learner_fanout(pg_world, register, _flat_numel(args.algorithm, n_action), device,
+                                  keep_register=args.register_actors != 0)
+    elif world > 1:
+        from ..parallel.dist import Dist
+        dist = Dist(device=device)
     hb_table, hb = None, None
     if args.transport == 'shm':
         from .heartbeat import HeartbeatTable
@@ -205,7 +242,7 @@ def learner_main(argv=None) -> int:
     try:
         if engine == 'hip':
             from ..engine.learner import run_hip_learner
-            return run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device)
+            return run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=dist)
         from .learner import Learner, load_checkpoint
         if args.algorithm == 'ape_x':
             model, target = DuelingDQN(n_action).to(device), DuelingDQN(n_action).to(device)
@@ -215,10 +252,7 @@ def learner_main(argv=None) -> int:
             target = DuelingLSTMDQN(n_action, cfg.batch_size, cfg.burn_in, cfg.nstep).to(device)
             opt = optim.Adam(model.parameters(), lr=cfg.lr, eps=cfg.adam_eps)                             # learner_node.py:40
         start = load_checkpoint(args.resume, model, target, opt) if args.resume else 0
-        dist = None
-        if world > 1:
-            from ..parallel.dist import Dist
-            dist = Dist(device=device)
+        if dist is not None:
             with torch.no_grad():                          # identical initial weights on every rank
                 for p_ in model.parameters():
                     dist.broadcast_flat(p_.data)
@@ -237,10 +271,14 @@ def learner_main(argv=None) -> int:
             hb.close()
         exp.close()
         par.close()
-        if register is not None:
+        if register is not None and getattr(par, "register", None) is not register:
             register.close()
         if hb_table is not None:
             hb_table.close()
+        if dist is not None:
+            dist.close()
+        if pg_world is not None:
+            pg_world.close()
     return 0
 
 

@@ -44,8 +44,16 @@ class ExperienceChannel:
 
 
 class ParamChannel:
+    # what ``publish2`` wants from a GPU learner: a host copy of the flat parameters, the device tensor itself, or both
+    wants_host, wants_device = True, False
+
     def publish(self, flat: np.ndarray) -> int:
         raise NotImplementedError
+
+    def publish2(self, host: Optional[np.ndarray], dev=None) -> int:
+        """Publication by a learner that holds the parameters on a GPU (engine/learner.py): ``host`` is given when
+        ``wants_host``, ``dev`` (a snapshot tensor the channel may read until it returns) when ``wants_device``."""
+        return self.publish(host)
 
     def pull(self, have_version: int = 0) -> Optional[Tuple[int, np.ndarray]]:
         """Return ``(version, flat fp32 params)`` if something newer than ``have_version`` exists."""

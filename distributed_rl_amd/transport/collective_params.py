@@ -13,6 +13,10 @@ like the reference's ``SET params`` (ape_x/learner.py:83), but without touching 
 Give it its OWN process group (``group=torch.distributed.new_group(...)``) when the learner captures its gradient
 all-reduce into the step graph: eager collectives of a group whose RCCL stream is being captured make the group's
 watchdog abort the process (``Dist.quiesce`` in parallel/dist.py explains the mechanism).
+
+Next to data-parallel learners the channel is a LANE of the launcher's world (runtime/placement.py, parallel/world.py):
+``group`` = the lane's sub-group, ``src_rank`` = the WORLD rank of the lane's learner. ``FanoutParams`` is the learner's
+side of a whole placement: the shard's register for co-located actors plus every lane that starts at this rank.
 """
 from __future__ import annotations
 
@@ -29,11 +33,15 @@ from . import ParamChannel
 class CollectiveParams(ParamChannel):
     def __init__(self, numel: int, src_rank: int = 0, group=None, device: Optional[torch.device] = None,
                  start: bool = True):
-        assert td.is_initialized(), "init the process group first (parallel.dist.Dist)"
+        """``src_rank``: rank of the publisher in the DEFAULT group (what ``torch.distributed.broadcast`` expects)."""
+        assert td.is_initialized(), "init the process group first (parallel.dist.Dist / parallel.world.join_world)"
         self.numel, self.src, self.group = int(numel), int(src_rank), group
-        self.rank = td.get_rank(group)
+        self.rank = td.get_rank()
         self.is_source = self.rank == self.src
-        self.device = device or torch.device("cpu")
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.wants_device = self.device.type == "cuda"       # the GPU learner hands over its device snapshot: no D2H/H2D
+        self.wants_host = not self.wants_device
+        self.last_publish_us = 0.0
         self._hdr = torch.zeros(2, dtype=torch.int64, device=self.device)
         self._stage = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         self._cur = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
@@ -56,9 +64,10 @@ class CollectiveParams(ParamChannel):
         td.broadcast(self._hdr, src=self.src, group=self.group)
         self._stage.copy_(t.reshape(-1).to(self.device, torch.float32), non_blocking=True)
         td.broadcast(self._stage, src=self.src, group=self.group)
-        with self._lock:
-            self._cur.copy_(self._stage)
         return self._v
+
+    def publish2(self, host, dev=None) -> int:
+        return self.publish(dev if (self.wants_device and dev is not None) else host)
 
     # ---- actor side -------------------------------------------------------------------------------
     def _recv_loop(self) -> None:
@@ -121,3 +130,43 @@ class CollectiveParams(ParamChannel):
             td.broadcast(self._hdr, src=self.src, group=self.group)
         elif self._thread is not None:
             self._thread.join(timeout=30)
+
+
+class FanoutParams(ParamChannel):
+    """Learner side of a placement: ONE publication reaches the shard's register (actors on this learner's GPU or on
+    the CPU) and every broadcast lane that starts at this rank (actors on other GPUs). Versions are the register's when
+    there is one (they are what co-located actors compare against), else the first lane's."""
+
+    def __init__(self, register: Optional[ParamChannel], lanes):
+        self.register, self.lanes = register, list(lanes)
+        self.wants_host = register is not None or any(l.wants_host for l in self.lanes)
+        self.wants_device = any(l.wants_device for l in self.lanes)
+
+    def publish(self, flat) -> int:
+        host = flat if not isinstance(flat, torch.Tensor) else flat.detach().float().cpu().numpy()
+        return self.publish2(host, flat if isinstance(flat, torch.Tensor) and flat.is_cuda else None)
+
+    def publish2(self, host, dev=None) -> int:
+        v = 0
+        if self.register is not None:
+            v = self.register.publish(host)
+        for lane in self.lanes:
+            lv = lane.publish2(host, dev)
+            v = v or lv
+        return v
+
+    def pull(self, have_version: int = 0):
+        return self.register.pull(have_version) if self.register is not None else None
+
+    def version(self) -> int:
+        return self.register.version() if self.register is not None else (self.lanes[0].version() if self.lanes else 0)
+
+    def reset(self) -> None:
+        if self.register is not None:
+            self.register.reset()
+
+    def close(self) -> None:
+        for lane in self.lanes:
+            lane.close()
+        if self.register is not None:
+            self.register.close()

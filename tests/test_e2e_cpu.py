@@ -141,3 +141,30 @@ def test_run_sh_collective_param_channel(tmp_path, run_id):
             if rec["name"].startswith("Params version"):
                 versions.append(rec["y"])
     assert versions and max(versions) >= 1, (versions, r.stdout[-2000:])      # the broadcast reached the actors
+
+
+def test_run_sh_data_parallel_learners_with_collective_param_channel(tmp_path, run_id):
+    """BASELINE config 3 in one run: `learner_gpus=2` AND `param_channel=collective`. Learner ranks and
+    actors form ONE torch.distributed world (gloo on CPU); the learners' gradient all-reduce runs in their own sub-group,
+    every learner rank broadcasts parameters to the actors of ITS shard over its own lane (runtime/placement.py)."""
+    conf = tmp_path / "dpc.conf"
+    conf.write_text("actor=true\nlearner=true\nvisdom=false\nalgorithm=ape_x\nredis_server=localhost\n"
+                    "visdom_server=localhost\nactor_device=cpu\nlearner_gpus=2\nparam_channel=collective\nparam_backend=gloo\n")
+    save, logs = tmp_path / "models", tmp_path / "logs"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DRL_NUM_ENVS="2")
+    cmd = [os.path.join(ROOT, "run.sh"), "4", str(conf), "", "--run-id", run_id, "--timeout", "280",
+           "--learner-args", "--max-steps 8 --batch-size 16 --start-memory-size 32 --save-timing 5 --save-dir %s --quiet --device cpu --engine torch" % save,
+           "--actor-args", "--quiet --device cpu --actor-batch 16 --param-period 4 --log-dir %s" % logs]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=330)
+    assert "learner exited with 0" in r.stdout and "learner_r1 exited with 0" in r.stdout, r.stdout[-3000:]
+    assert "lane 0 <- learner rank 0" in r.stdout and "lane 1 <- learner rank 1" in r.stdout, r.stdout[-3000:]
+    assert os.path.exists(save / "model_5.pth"), r.stdout[-3000:]
+    assert not glob.glob("/dev/shm/drl_%s*" % run_id)
+    import json
+    seen = {}
+    for f in glob.glob(str(logs / "actor_*.jsonl")):
+        for line in open(f):
+            rec = json.loads(line)
+            if rec["name"].startswith("Params version"):
+                seen[rec["name"]] = max(seen.get(rec["name"], 0), rec["y"])
+    assert len(seen) == 4 and min(seen.values()) >= 1, (seen, r.stdout[-2000:])   # every actor of BOTH shards was reached
