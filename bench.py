@@ -304,7 +304,11 @@ def run_rank(args) -> int:
             from distributed_rl_amd.replay.device_seq import DeviceSequenceReplay
             rcfg = R2D2Config()
             free, _ = torch.cuda.mem_get_info(dev)
-            scap = min(100_000, int(free * 0.6 // (123 * 7056 + 8192) // share))     # T + 3 planes per sequence: 87 GB
+            from distributed_rl_amd.replay.device_seq import sequences_that_fit
+            # neighbouring sequences share their planes (~44 each instead of 123): 100 K paper-shape sequences are ~34 GB
+            fit = sequences_that_fit(free, rcfg) // share
+            scap = min(100_000, fit)
+            extra["r2d2_replay_sequences_that_would_fit"] = fit
             srep = DeviceSequenceReplay(scap, dev, rcfg, seed=dist.rank)
             srep.fill_synthetic(scap, n_action=args.n_action, seed=dist.rank)
             reng = R2D2Engine(args.n_action, rcfg, srep, dev, dist=dist)

@@ -79,6 +79,9 @@ class SequenceItem(NamedTuple):
     length: int
     h0: np.ndarray         # (H,) recurrent state *before* frames[0]  (r2d2/actor.py:39,57)
     c0: np.ndarray
+    env: int = -1          # source env of a vectorised actor
+    q: Optional[np.ndarray] = None   # (T_total,) int64: positions of the observations in the env's plane stream (PlaneLog)
+                                     # when the assembler keeps no frames (``frames`` is then None)
 
 
 class SequenceAssembler:

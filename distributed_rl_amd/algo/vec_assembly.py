@@ -113,6 +113,21 @@ class PlaneLog:
         return self.P[e, np.arange(q0, q1 + 1) % self.cap]
 
 
+def sequence_plane_block(log: PlaneLog, e: int, seqs):
+    """(planes [M,H,W], win [K,T] int32) of sequences of ONE env assembled without frames (``SequenceItem.q``): the planes
+    they span once - overlapping sequences share theirs - and, per step, the pool index of the first plane of its window."""
+    lo = min(int(s.q[:s.length].min()) for s in seqs)
+    hi = max(int(s.q[:s.length].max()) for s in seqs) + log.stack - 1
+    win = np.stack([np.clip(s.q - lo, 0, hi - lo - log.stack + 1) for s in seqs]).astype(np.int32)
+    return log.planes(e, lo, hi), win
+
+
+def stacks_from_planes(planes: np.ndarray, win: np.ndarray, stack: int = 4) -> np.ndarray:
+    """HWC observation stacks [..., H, W, stack] of the windows ``win`` (any shape) over a plane pool [M, H, W]."""
+    idx = np.asarray(win)[..., None] + np.arange(stack)
+    return np.ascontiguousarray(np.moveaxis(planes[idx], -3, -1))
+
+
 def plane_block(log: PlaneLog, env: np.ndarray, qs: np.ndarray, qs2: np.ndarray):
     """(planes [M,H,W], win_s [K], win_s2 [K]) of the transitions (env, qs, qs2): per env the planes its transitions span,
     once; win = index of a window's first plane in the pool."""
@@ -217,7 +232,10 @@ class VecSequenceAssembler:
     SLOTS = 4        # live sequence starts per env: ceil(T_total / stride) + 1 never exceeds this for overlap < seq_len/…
 
     def __init__(self, num_envs: int, nstep: int, gamma: float, burn_in: int = 40, seq_len: int = 80, overlap: int = 40,
-                 reference_order: bool = False, flush_tail: bool = True, hidden: int = 512):
+                 reference_order: bool = False, flush_tail: bool = True, hidden: int = 512, store_states: bool = True):
+        """store_states=False: the caller keeps every frame in a PlaneLog and passes the observations' stream positions
+        (``q_state``); sequences then carry positions (``SequenceItem.q``, ``.env``) and no frames - nothing is copied here
+        (a 28 KB stack per env and step into the sequence buffers, and 3.4 MB per emitted sequence, otherwise)."""
         assert seq_len > 1, "n_sequence must be more than 1."
         assert overlap < seq_len, "n_overlap must be less than n_sequence."
         self.E, self.n, self.gamma = num_envs, nstep, gamma
@@ -228,7 +246,9 @@ class VecSequenceAssembler:
         self.ring = _StepRing(num_envs, nstep)
         self.w = _weights(nstep, gamma, reference_order)
         E, T = num_envs, self.total
+        self.store_states = store_states
         self.F: Optional[np.ndarray] = None                      # [E, T, ...] frames of the sequence being assembled
+        self.Q = np.zeros((E, T), dtype=np.int64)                # ... or their positions in the env's plane stream
         self.A = np.zeros((E, T), dtype=np.int64)
         self.R = np.zeros((E, T), dtype=np.float32)
         self.D = np.zeros((E, T), dtype=np.float32)
@@ -247,35 +267,45 @@ class VecSequenceAssembler:
     # ---- internals -----------------------------------------------------------------------------------------------
     def _emit(self, e: int, out: List[SequenceItem]) -> None:
         L = int(self.len[e])
-        frames = np.zeros((self.total,) + self.F.shape[2:], dtype=self.F.dtype)
-        frames[:L] = self.F[e, :L]
+        frames = q = None
+        if self.store_states:
+            frames = np.zeros((self.total,) + self.F.shape[2:], dtype=self.F.dtype)
+            frames[:L] = self.F[e, :L]
+        else:                                                     # padding steps point at the last real observation
+            q = np.concatenate([self.Q[e, :L], np.full(self.total - L, self.Q[e, L - 1], np.int64)])
         pad = lambda a: np.concatenate([a[e, :L], np.zeros(self.total - L, a.dtype)])   # noqa: E731
         slot = (self.ent0[e] // self.stride) % self.slots
         out.append(SequenceItem(frames, pad(self.A), pad(self.R), pad(self.D), L, self.start_h[e, slot].copy(),
-                                self.start_c[e, slot].copy()))
+                                self.start_c[e, slot].copy(), int(e), q))
 
     def _slide(self, e: int) -> None:
         k = self.keep
         if k > 0:
-            self.F[e, :k] = self.F[e, self.total - k:self.total]
-            for a in (self.A, self.R, self.D):
+            if self.store_states:
+                self.F[e, :k] = self.F[e, self.total - k:self.total]
+            for a in (self.A, self.R, self.D, self.Q):
                 a[e, :k] = a[e, self.total - k:self.total]
         self.len[e] = k
         self.ent0[e] += self.stride
 
-    def _push_one(self, e: int, frame, a, ret, d, out) -> None:
+    def _push_one(self, e: int, frame, a, ret, d, out, q=0) -> None:
         p = int(self.len[e])
-        self.F[e, p], self.A[e, p], self.R[e, p], self.D[e, p] = frame, a, ret, d
+        if self.store_states:
+            self.F[e, p] = frame
+        self.Q[e, p], self.A[e, p], self.R[e, p], self.D[e, p] = q, a, ret, d
         self.len[e] = p + 1
         if p + 1 == self.total:
             self._emit(e, out)
             self._slide(e)
 
-    def step(self, state, action, reward, done, h, c) -> List[SequenceItem]:
+    def step(self, state, action, reward, done, h, c, q_state=None) -> List[SequenceItem]:
         """``h`` / ``c``: recurrent state BEFORE ``state`` was consumed - either for every env, shape (E, H), or only for
-        the envs flagged by ``need_state()`` (rows in env order)."""
+        the envs flagged by ``need_state()`` (rows in env order). ``q_state`` ([E] int64): positions of ``state`` in the
+        envs' plane streams (PlaneLog.observe) - required with store_states=False."""
         r, n = self.ring, self.n
-        if self.F is None:
+        keep = self.store_states
+        assert keep or q_state is not None, "store_states=False needs the plane-stream positions"
+        if keep and self.F is None:
             self.F = np.zeros((self.E, self.total) + tuple(state.shape[1:]), dtype=state.dtype)
         need = np.nonzero(self.need_state())[0]
         if len(need):
@@ -285,7 +315,7 @@ class VecSequenceAssembler:
             slot = (self.ep_step[need] // self.stride) % self.slots
             self.start_h[need, slot] = h.reshape(len(need), -1)
             self.start_c[need, slot] = c.reshape(len(need), -1)
-        hd = r.write(state, action, reward)
+        hd = r.write(state if keep else None, action, reward, q_state)
         done = np.asarray(done, dtype=bool)
         out: List[SequenceItem] = []
         ready = np.nonzero(r.cnt == n)[0]
@@ -294,7 +324,9 @@ class VecSequenceAssembler:
             order = (old + np.arange(n)) % n
             ret = (self.w[:, None] * r.R[order][:, ready]).sum(0)
             pos = self.len[ready]
-            self.F[ready, pos] = r.S[old, ready]
+            if keep:
+                self.F[ready, pos] = r.S[old, ready]
+            self.Q[ready, pos] = r.Q[old, ready]
             self.A[ready, pos] = r.A[old, ready]
             self.R[ready, pos] = ret
             self.D[ready, pos] = done[ready]
@@ -311,7 +343,8 @@ class VecSequenceAssembler:
                     tail = sl[j:]
                     k = np.arange(len(tail))
                     w = self.gamma ** (n - 1 - k) if self.reference_order else self.gamma ** k
-                    self._push_one(e, r.S[tail[0], e], r.A[tail[0], e], float((w * r.R[tail, e]).sum()), 1.0, out)
+                    self._push_one(e, r.S[tail[0], e] if keep else None, r.A[tail[0], e], float((w * r.R[tail, e]).sum()), 1.0,
+                                   out, r.Q[tail[0], e])
             if self.len[e] > self.keep + n:
                 self._emit(e, out)                                 # the shorter tail sequence (r2d2/actor.py:61-63)
             self.len[e] = 0

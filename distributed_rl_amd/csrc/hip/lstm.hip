@@ -35,6 +35,16 @@ __global__ void k_seq_offsets(const int* __restrict__ idx, int B, int T, long lo
     off[i] = (long long)idx[b] * seq_bytes + (long long)t * plane_bytes;
 }
 
+// the same for a store that shares planes between sequences (replay/device_seq.py): every slot keeps a row of T window
+// offsets, off[t*B + b] = win[idx[b]][t]
+__global__ void k_seq_win_offsets(const int* __restrict__ idx, const long long* __restrict__ win, int B, int T,
+                                  long long* __restrict__ off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;                 // consecutive threads read consecutive words of a row
+    off[t * B + b] = win[(long long)idx[b] * T + t];
+}
+
 // dst[b][:] = src[idx[b]][:]  (f32 rows -> f32 and bf16 copies): stored recurrent state of the sampled sequences
 __global__ void k_gather_state(const float* __restrict__ src, const int* __restrict__ idx, int B, int H,
                                float* __restrict__ dst_f32, bf16_t* __restrict__ dst_bf16) {
@@ -76,6 +86,11 @@ DRL_API int drl_lstm_bwd_point(const void* dh_head, float* dh_rec, float* dc, co
 DRL_API int drl_seq_offsets(const int* idx, int B, int T, long long seq_bytes, long long plane_bytes, long long* off, hipStream_t s) {
     if (B <= 0 || T <= 0) return -1;
     k_seq_offsets<<<(B * T + 255) / 256, 256, 0, s>>>(idx, B, T, seq_bytes, plane_bytes, off);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_seq_win_offsets(const int* idx, const long long* win, int B, int T, long long* off, hipStream_t s) {
+    if (B <= 0 || T <= 0) return -1;
+    k_seq_win_offsets<<<(B * T + 255) / 256, 256, 0, s>>>(idx, win, B, T, off);
     return (int)hipGetLastError();
 }
 DRL_API int drl_gather_state(const float* src, const int* idx, int B, int H, float* dst_f32, void* dst_bf16, hipStream_t s) {

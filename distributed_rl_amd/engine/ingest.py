@@ -37,12 +37,12 @@ from ..transport import codec
 
 
 class _Staged:
-    __slots__ = ("buf", "meta", "fields", "blk", "K", "done", "retired_at")
+    __slots__ = ("buf", "meta", "fields", "blk", "K", "done", "retired_at", "need")
 
     def __init__(self, buf, meta, fields):
         self.buf, self.meta, self.fields = buf, meta, fields
         self.K = int(meta["K"])
-        self.blk, self.done, self.retired_at = None, None, -1
+        self.blk, self.done, self.retired_at, self.need = None, None, -1, None
 
 
 class AsyncIngest:
@@ -123,6 +123,9 @@ class AsyncIngest:
             assert used == meta["bytes"]
             self.stage_s += time.perf_counter() - t0
         rec = _Staged(b, meta, fields)
+        # how much of the replay's rings the block takes - decided HERE, off the learner's thread: blocks of full stacks
+        # are checked on their pixels for it (replay/device_seq.py stack_block_planes)
+        rec.need = self.replay.block_need(int(meta["kind"]), rec.K, int(meta.get("M", 0)), self._views(rec))
         return rec
 
     # ---- learner thread ------------------------------------------------------------------------------------------
@@ -174,7 +177,7 @@ class AsyncIngest:
                 break
             if rec.K > self._prio[rec.buf].numel():
                 self._prio[rec.buf] = torch.zeros(rec.K, device=self.device)
-            K, M = r.block_need(int(rec.meta["kind"]), rec.K, int(rec.meta.get("M", 0)))
+            K, M = rec.need
             rec.blk = r.reserve_block(K, M)           # ranges of the replay's rings; whatever owned them leaves the tree
             rec.retired_at = self._tick
             self._retired.append(rec)

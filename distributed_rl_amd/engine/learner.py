@@ -155,13 +155,14 @@ class HipLearner:
     def _fit_capacity(self, want: int, cfg) -> int:
         """The replay lives in HBM: clamp the requested item count to what fits next to the engine's activations (75 %
         of the free memory). With every frame stored once the reference's default ``-s 100000`` - 100 000 SEQUENCES for
-        R2D2 - is 87 GB (full stacks: 315 GiB), and an MI355X holds ~20 M Ape-X transitions."""
+        R2D2 - is ~34 GB (full stacks: 315 GiB), and an MI355X holds ~20 M Ape-X transitions."""
         import warnings
         if self.device.type != "cuda":
             return want
         free, _ = torch.cuda.mem_get_info(self.device)
-        if self.is_r2d2:                 # T + 3 single planes per sequence (replay/device_seq.py)
-            per_item = (cfg.total_len + 3) * 7056 + cfg.total_len * 16 + 2 * 4 * cfg.hidden + 64
+        if self.is_r2d2:                 # ~48 planes per sequence: neighbours share theirs (replay/device_seq.py)
+            from ..replay.device_seq import planes_per_sequence
+            per_item = int(planes_per_sequence(cfg) * 1.08 * 7056) + cfg.total_len * 20 + 2 * 4 * cfg.hidden + 64
         else:                            # ~1.3 planes per transition (replay/device_per.py) + tables
             per_item = int(float(os.environ.get("DRL_PLANES_PER_ITEM", "1.3")) * 7056) + 64
         fit = int(free * 0.75 // per_item)

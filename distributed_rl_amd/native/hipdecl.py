@@ -59,6 +59,7 @@ SIGS = {
     "drl_lstm_bwd_point": [P, P, P, P, P, P, P, I, I, P],
     "drl_lstm_bwd_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "drl_seq_offsets": [P, I, I, L, L, P, P],
+    "drl_seq_win_offsets": [P, P, I, I, P, P],
     "drl_gather_state": [P, P, I, I, P, P, P],
     "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P],
     "drl_add2": [P, P, P, I, P],

@@ -827,6 +827,14 @@ def seq_offsets(idx, T: int, seq_bytes: int, plane_bytes: int, off) -> None:
     _ck(native.hip().drl_seq_offsets(_p(idx), idx.numel(), T, seq_bytes, plane_bytes, _p(off), _s()), "seq_offsets")
 
 
+def seq_win_offsets(idx, win, T: int, off) -> None:
+    """off[t * B + b] = win[idx[b], t]: time-major plane-window byte offsets of a sampled sequence batch from the replay's
+    per-slot window table (sequences that share planes: replay/device_seq.py)."""
+    _chk(idx, torch.int32, "idx"); _chk(win, torch.int64, "win"); _chk(off, torch.int64, "off")
+    assert win.shape[-1] == T and off.numel() >= idx.numel() * T
+    _ck(native.hip().drl_seq_win_offsets(_p(idx), _p(win), idx.numel(), T, _p(off), _s()), "seq_win_offsets")
+
+
 def gather_state(src, idx, dst_f32=None, dst_bf16=None) -> None:
     _chk(src, torch.float32, "src"); _chk(idx, torch.int32, "idx")
     _ck(native.hip().drl_gather_state(_p(src), _p(idx), idx.numel(), src.shape[-1], _p(dst_f32), _p(dst_bf16), _s()), "gather_state")

@@ -176,10 +176,25 @@ class Dist:
         """The engine that owned the direct all-reduce's buffer is gone: the next ``grad_buffer`` call may have it."""
         self._xgmi_busy = False
 
+    def _device_collectives(self) -> bool:
+        """Can this group reduce DEVICE tensors natively (RCCL)? gloo accepts them too, but its CUDA path has deadlocked on
+        back-to-back collectives when the ranks of a rehearsal share one GPU: such groups reduce through host tensors."""
+        return self.device.type == "cuda" and "nccl" in str(self.backend)
+
+    def _reduce(self, t: torch.Tensor, op) -> torch.Tensor:
+        """In-place all-reduce of a small / set-up-time tensor that works on every backend (see _device_collectives)."""
+        if t.is_cuda and not self._device_collectives():
+            h = t.detach().cpu()
+            td.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            td.all_reduce(t, op=op, group=self.group)
+        return t
+
     def _agree(self, ok: bool) -> bool:
         """Same verdict on every rank (MIN); a rank that cannot even take the collective votes no."""
         try:
-            v = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            v = torch.tensor([1.0 if ok else 0.0], device=self.device if self._device_collectives() else "cpu")
             td.all_reduce(v, op=td.ReduceOp.MIN, group=self.group)
             return float(v.item()) > 0.5
         except Exception:                                       # noqa: BLE001
@@ -206,7 +221,7 @@ class Dist:
             ar.flat[numel - sh:numel].copy_(noise[:sh])
             ar.flat[:numel].mul_(1.0 + 0.125 * (k % 5))
             want.copy_(ar.flat)
-            td.all_reduce(want, op=td.ReduceOp.SUM, group=self.group)
+            self._reduce(want, td.ReduceOp.SUM)
             torch.cuda.synchronize(self.device)
             try:
                 if k % 2 == 0:
@@ -247,8 +262,10 @@ class Dist:
         for nb in cands:
             ar.set_blocks(nb)
             out.append(clock(lambda: ar.all_reduce(ar.flat[:numel], channel=2)))
-        out.append(clock(lambda: td.all_reduce(tmp, op=td.ReduceOp.SUM, group=self.group)))
-        v = torch.tensor(out, dtype=torch.float64, device=self.device)
+        out.append(clock(lambda: self._reduce(tmp, td.ReduceOp.SUM)))
+        v = torch.tensor(out, dtype=torch.float64)
+        if self._device_collectives():
+            v = v.to(self.device)
         td.all_reduce(v, op=td.ReduceOp.MAX, group=self.group)
         ts = [float(x) for x in v.tolist()]
         best = min(range(len(cands)), key=lambda i: ts[i])

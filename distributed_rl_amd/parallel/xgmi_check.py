@@ -65,6 +65,10 @@ def engine_check(r2d2: bool) -> int:
 
 
 def main() -> int:
+    wd = float(os.environ.get("DRL_BENCH_WATCHDOG", "0"))
+    if wd > 0:                               # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     if "--engine" in sys.argv or "--engine-r2d2" in sys.argv:
         return engine_check("--engine-r2d2" in sys.argv)
     ap = argparse.ArgumentParser()

@@ -24,34 +24,20 @@ and split into 8 planes per transition on the device.
 """
 from __future__ import annotations
 
-from collections import deque
-from typing import Deque, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from ..ops import hip as H
+from .rings import Block as _Block, RingPair
 
 PLANE_BYTES = 84 * 84
 STACK = 4
 FRAME_BYTES = PLANE_BYTES * STACK        # one stacked observation as the environments deliver it (HWC)
 
 
-class _Block:
-    """One ingested block: the contiguous slot and plane ranges it owns. state: 0 = reserved (its data may still be on
-    the way: engine/ingest.py keeps several blocks in flight), 1 = committed (in the tree), 2 = evicted before its commit
-    (a replay smaller than what is in flight): the commit is then dropped."""
-    __slots__ = ("slot", "K", "plane", "M", "state")
-
-    def __init__(self, slot: int, K: int, plane: int, M: int):
-        self.slot, self.K, self.plane, self.M, self.state = slot, K, plane, M, 0
-
-
-def _overlap(a0: int, a1: int, b0: int, b1: int) -> bool:
-    return a0 < b1 and b0 < a1
-
-
-class DevicePER:
+class DevicePER(RingPair):
     def __init__(self, capacity: int, device="cuda", batch_size: int = 512, seed: int = 0,
                  planes_per_item: float = 1.3, plane_capacity: Optional[int] = None, max_ingest: int = 4096):
         self.capacity = int(capacity)
@@ -72,10 +58,8 @@ class DevicePER:
         self.done = torch.zeros(self.capacity, device=dev)
         self.n_items = torch.zeros(1, dtype=torch.int64, device=dev)
         self._scratch = torch.zeros(max(max_ingest, 64), dtype=torch.int32, device=dev)
-        self.cursor = 0              # next transition slot
-        self.pcursor = 0             # next plane
-        self.count = 0               # live transitions (host view; n_items is the device copy)
-        self._blocks: Deque[_Block] = deque()
+        self._init_rings()           # cursor / pcursor / count (host view; n_items is the device copy) / block deque
+        self._warned_planes = False
         # sample outputs (fixed addresses: graph-capturable)
         B = batch_size
         self.idx = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -114,37 +98,21 @@ class DevicePER:
     # reserve_block (ranges of both rings; everything that still owns part of them leaves the tree: nothing samples it any
     # more), write_block (the data, any stream), commit_block (priorities + generation + item count, one launch).
     def _retire(self, slot: int, K: int) -> None:
-        H.sumtree_ingest(self.tree, self.lay, slot, None, self.gen, self._scratch, n=K)
+        H.sumtree_ingest(self.tree, self.lay, slot, None, self.gen, self._scratch, n=K, n_items=self.n_items,
+                         n_items_val=self.count)
 
     def reserve_block(self, K: int, M: int) -> _Block:
-        if K > self.capacity or M > self.plane_capacity:
-            raise ValueError("block larger than the replay")
         if K > self._scratch.numel():
             self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
-        # contiguous ranges: a range that does not fit before the end of its ring starts over at 0, and the skipped tail
-        # counts as overwritten too - both rings then stay in ingestion order, so the blocks in the way are always the
-        # OLDEST ones (front of the deque)
-        slot = self.cursor if self.cursor + K <= self.capacity else 0
-        plane = self.pcursor if self.pcursor + M <= self.plane_capacity else 0
-        s_rng = [(slot, slot + K)] + ([(self.cursor, self.capacity)] if slot != self.cursor else [])
-        p_rng = [(plane, plane + M)] + ([(self.pcursor, self.plane_capacity)] if plane != self.pcursor else [])
-
-        def in_the_way(b: _Block) -> bool:
-            return any(_overlap(b.slot, b.slot + b.K, lo, hi) for lo, hi in s_rng) or \
-                any(_overlap(b.plane, b.plane + b.M, lo, hi) for lo, hi in p_rng)
-
-        while self._blocks and in_the_way(self._blocks[0]):
-            b = self._blocks.popleft()
-            if b.state == 1:
-                self._retire(b.slot, b.K)                         # FIFO eviction, whole blocks
-                self.count -= b.K
-            b.state = 2
-        if slot != self.cursor or plane != self.pcursor:          # once per lap: the order argument, checked
-            assert not any(in_the_way(b) for b in self._blocks), "replay rings out of ingestion order"
-        self.cursor, self.pcursor = slot + K, plane + M
-        blk = _Block(slot, K, plane, M)
-        self._blocks.append(blk)                                  # owner of its ranges from now on
-        return blk
+        if M > 2 * STACK * K - 1 and not self._warned_planes and M * self.capacity > 2 * K * self.plane_capacity:
+            # producers that send full stacks (codec kind 1: 8 planes per transition) into a plane ring sized for plane-pool
+            # blocks (~1.3): whole blocks are evicted early and the replay holds far fewer items than its capacity says
+            import warnings
+            self._warned_planes = True
+            warnings.warn("replay: blocks carry %.1f planes per transition but the plane ring was sized for %.1f: at most ~%d "
+                          "of the %d transitions stay resident (size it with planes_per_item / DRL_PLANES_PER_ITEM)"
+                          % (M / K, self.plane_capacity / self.capacity, self.plane_capacity * K // M, self.capacity))
+        return RingPair.reserve_block(self, K, M)
 
     def write_block(self, blk: _Block, planes: torch.Tensor, win_s: torch.Tensor, win_s2: torch.Tensor, action: torch.Tensor,
                     reward: torch.Tensor, done: torch.Tensor) -> None:
@@ -189,7 +157,7 @@ class DevicePER:
 
     # block-kind dispatch used by engine/ingest.py (views of one staged block) and ingest_block (decoded arrays)
     @staticmethod
-    def block_need(kind: int, K: int, M: int = 0) -> Tuple[int, int]:
+    def block_need(kind: int, K: int, M: int = 0, views=None) -> Tuple[int, int]:
         from ..transport import codec
         return (K, M) if kind == codec.KIND_APEX_PLANES else (K, 2 * STACK * K)
 

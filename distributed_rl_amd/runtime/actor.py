@@ -26,7 +26,8 @@ import numpy as np
 import torch
 
 from ..algo.nstep import SequenceItem
-from ..algo.vec_assembly import PlaneLog, VecNStepAssembler, VecSequenceAssembler, plane_block
+from ..algo.vec_assembly import (PlaneLog, VecNStepAssembler, VecSequenceAssembler, plane_block, sequence_plane_block,
+                                 stacks_from_planes)
 from ..config import ApexConfig, R2D2Config
 from ..models.packing import ParamPack
 from ..transport import ExperienceChannel, ParamChannel, codec
@@ -138,6 +139,10 @@ class _LocalPlaneBuffer:
         r = np.nonzero(self.n >= k)[0]
         return int(r[0]) if len(r) else None
 
+    def oldest_q(self) -> np.ndarray:
+        """Stream position of every env's oldest buffered transition (a huge value where nothing is buffered)."""
+        return np.where(self.n > 0, self.qs[:, 0], np.iinfo(np.int64).max)
+
     def take(self, e: int, k: int):
         out = dict(qs=self.qs[e, :k].copy(), qs2=self.qs2[e, :k].copy(), action=self.action[e, :k].copy(),
                    reward=self.reward[e, :k].copy(), done=self.done[e, :k].copy())
@@ -170,10 +175,19 @@ class Actor:
             self.target.eval()
             self.net.hx = torch.zeros(self.E, self.net.hidden, device=device)
             self.net.cx = torch.zeros(self.E, self.net.hidden, device=device)
+            # every frame once on the wire and in the replay, across the overlapping sequences of an env too: the frames
+            # live in a per-env plane log, sequences are rows of positions, and an env publishes its finished sequences
+            # together with the planes they span (codec kind 4). DRL_PLANE_BLOCKS=0: full stacks per step (kind 2).
+            self.plane_log = None
+            if os.environ.get("DRL_PLANE_BLOCKS", "1") != "0":
+                stride = cfg.seq_len - cfg.overlap
+                cap = int(os.environ.get("DRL_SEQ_LOG_PLANES", "0")) or (stride * cfg.actor_batch + cfg.total_len + 64)
+                self.plane_log = PlaneLog(self.E, cap=cap)
             self.asm = VecSequenceAssembler(self.E, cfg.nstep, cfg.gamma, cfg.burn_in, cfg.seq_len, cfg.overlap,
                                             cfg.reference_nstep_order, flush_tail=not cfg.reference_nstep_order,
-                                            hidden=self.net.hidden)
+                                            hidden=self.net.hidden, store_states=self.plane_log is None)
             self.local: List[SequenceItem] = []
+            self.local_env: List[List[SequenceItem]] = [[] for _ in range(self.E)]      # plane mode: finished sequences per env
         else:
             self.asm = VecNStepAssembler(self.E, cfg.nstep, cfg.gamma, cfg.reference_nstep_order,
                                          flush_tail=not cfg.reference_nstep_order)
@@ -188,6 +202,7 @@ class Actor:
         self.env_steps = 0
         self.published_blocks = 0
         self.dropped_blocks = 0
+        self.lost_to_plane_log = 0        # transitions whose planes had left the plane log (must stay 0: _urgent_envs)
         self.episodes = 0
         self.render_every = render_every
         if metrics is not None:
@@ -235,15 +250,16 @@ class Actor:
 
     # ---- publishing -------------------------------------------------------------------------------
     @torch.no_grad()
-    def _publish_apex_planes(self, e: int) -> None:
-        """One env's next ``actor_batch`` transitions as a plane-pool block: the planes they span once + two window
-        positions each; initial priorities from the same pool (no stack is ever materialised on the engine path)."""
-        cfg, t = self.cfg, self.local.take(e, self.cfg.actor_batch)
+    def _publish_apex_planes(self, e: int, k: Optional[int] = None) -> None:
+        """One env's next ``actor_batch`` (or ``k``) transitions as a plane-pool block: the planes they span once + two
+        window positions each; initial priorities from the same pool (no stack is ever materialised on the engine path)."""
+        cfg, t = self.cfg, self.local.take(e, self.cfg.actor_batch if k is None else k)
         K = len(t["action"])
         try:
             planes, win_s, win_s2 = plane_block(self.plane_log, np.full(K, e), t["qs"], t["qs2"])
-        except IndexError:                                   # outlived the plane log (cannot happen with its default size)
+        except IndexError:                  # outlived the plane log: _urgent_envs() publishes before this can happen
             self.dropped_blocks += 1
+            self.lost_to_plane_log += K
             return
         if self.engine is not None:
             prio = self.engine.priorities_planes(planes, win_s, win_s2, t["action"], t["reward"], t["done"], cfg.gamma_n,
@@ -260,6 +276,16 @@ class Actor:
                         prio=prio), codec.KIND_APEX_PLANES)
 
     @torch.no_grad()
+    def _urgent_envs(self) -> np.ndarray:
+        """Envs whose oldest buffered transition is about to leave the plane log. The log is sized for environments that
+        shift their stack by one frame per step (1 new plane per step); one that does not (``SyntheticRandom-v0``, a
+        non-stacking env, a frame-skip mismatch) appends up to 2 x stack planes per step, so a full ``actor_batch`` would
+        outlive the ring. Such envs publish what they have NOW, as a shorter block - nothing is ever dropped for the
+        log's sake, and the memory stays what the common case needs."""
+        log = self.plane_log
+        margin = 2 * log.stack * (self.cfg.nstep + 3)
+        return np.nonzero(log.head - self.local.oldest_q() > log.cap - margin)[0]
+
     def _publish_apex(self) -> None:
         blk = self.local.take(self.cfg.actor_batch)
         dev = self.device
@@ -300,6 +326,55 @@ class Actor:
                                   done_offset=self.cfg.nstep if self.cfg.reference_nstep_order else 0)
         prio = td.prio.float().cpu().numpy()
         self._send_sequences(seqs, prio)
+
+    @torch.no_grad()
+    def _publish_r2d2_planes(self, e: int, k: int) -> None:
+        """The next ``k`` finished sequences of env ``e`` as ONE plane-pool block: the planes they span once (consecutive
+        sequences overlap by burn_in + overlap steps, r2d2/actor.py:56-60) + a row of window positions per sequence;
+        priorities from the same pool (the engine reads plane windows in place, like the learner does)."""
+        cfg = self.cfg
+        seqs, self.local_env[e] = self.local_env[e][:k], self.local_env[e][k:]
+        try:
+            planes, win = sequence_plane_block(self.plane_log, e, seqs)
+        except IndexError:                  # outlived the plane log: _urgent_seq_envs() publishes before this can happen
+            self.dropped_blocks += 1
+            self.lost_to_plane_log += len(seqs)
+            return
+        action = np.stack([s.action for s in seqs]).astype(np.int32)
+        reward, done = np.stack([s.reward for s in seqs]), np.stack([s.done for s in seqs])
+        length = np.array([s.length for s in seqs], dtype=np.int32)
+        h0, c0 = np.stack([s.h0 for s in seqs]), np.stack([s.c0 for s in seqs])
+        if self.engine is not None:
+            prio = self.engine.sequence_priorities_planes(planes, win, action, reward, done, length, h0, c0)
+        else:
+            dev = self.device
+            frames = torch.from_numpy(stacks_from_planes(planes, win.T)).to(dev)               # (T, K, 84, 84, 4)
+            td = self.net.sequence_td(self.target, frames, torch.from_numpy(action.T.astype(np.int64)).to(dev),
+                                      torch.from_numpy(reward.T.copy()).to(dev), torch.from_numpy(done.T.copy()).to(dev),
+                                      torch.from_numpy(length).to(dev), torch.from_numpy(h0).to(dev), torch.from_numpy(c0).to(dev),
+                                      None, cfg.eta, cfg.gamma_n, cfg.rescale_eps, require_grad=False,
+                                      done_offset=cfg.nstep if cfg.reference_nstep_order else 0)
+            prio = td.prio.float().cpu().numpy()
+        blk = dict(planes=planes, win=win, action=action, reward=reward, done=done, length=length, h0=h0, c0=c0,
+                   prio=prio.astype(np.float32))
+        if codec.block_bytes(blk, codec.KIND_R2D2_PLANES) > getattr(self.exp, "slot_bytes", 1 << 62) and len(seqs) > 1:
+            # too large for a ring slot (many episode boundaries in the span): two blocks, each with the planes of its half
+            h = len(seqs) // 2
+            for a, b in ((0, h), (h, len(seqs))):
+                lo, hi = int(win[a:b].min()), int(win[a:b].max()) + self.plane_log.stack
+                part = {n_: v[a:b] for n_, v in blk.items() if n_ != "planes"}
+                part["planes"], part["win"] = planes[lo:hi], win[a:b] - lo
+                self._send(part, codec.KIND_R2D2_PLANES)
+            return
+        self._send(blk, codec.KIND_R2D2_PLANES)
+
+    def _urgent_seq_envs(self) -> np.ndarray:
+        """Envs whose oldest sequence (finished or still being assembled) is about to leave the plane log - an env that
+        adds more than one plane per step (see _urgent_envs): publish what is finished, now."""
+        log = self.plane_log
+        oldest = np.array([min([int(s.q[0]) for s in self.local_env[e]] or [np.iinfo(np.int64).max]) for e in range(self.E)])
+        margin = log.stack * (self.cfg.total_len // 4 + self.cfg.nstep + 3)
+        return np.nonzero((log.head - oldest > log.cap - margin) & (oldest < np.iinfo(np.int64).max))[0]
 
     def _send_sequences(self, seqs, prio) -> None:
         T, H = seqs[0].frames.shape[0], seqs[0].h0.shape[0]
@@ -355,7 +430,7 @@ class Actor:
         self.env.reset()
         scores = np.zeros(self.E)
         t = 0
-        log = None if self.is_r2d2 else self.plane_log
+        log = self.plane_log
         q_state = q_next = None
         t_rep, steps_rep = time.time(), self.env_steps
         while max_steps is None or t < max_steps:
@@ -372,7 +447,11 @@ class Actor:
             r = self._clip(reward)
             with ph("actor/assemble"):
                 if self.is_r2d2:
-                    self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
+                    if log is not None:
+                        for sq in self.asm.step(obs, action, r, done, h_before, c_before, log.observe(obs)):
+                            self.local_env[sq.env].append(sq)
+                    else:
+                        self.local.extend(self.asm.step(obs, action, r, done, h_before, c_before))
                     if done.any():
                         if self.engine is not None:
                             self.engine.reset(done)
@@ -395,12 +474,20 @@ class Actor:
                 rgb = getattr(self.env, "render_rgb", None)          # emulator screen when there is one, else the newest plane
                 self.metrics.image("Frame %s" % self.name, rgb(0) if rgb is not None else obs[0][..., -1])
             with ph("actor/publish"):
-                if log is not None:
+                if log is not None and self.is_r2d2:
+                    for e in range(self.E):
+                        while len(self.local_env[e]) >= cfg.actor_batch:
+                            self._publish_r2d2_planes(e, cfg.actor_batch)
+                    for e in self._urgent_seq_envs():
+                        self._publish_r2d2_planes(int(e), len(self.local_env[e]))
+                elif log is not None:
                     while True:
                         e = self.local.ready(cfg.actor_batch)
                         if e is None:
                             break
                         self._publish_apex_planes(e)
+                    for e in self._urgent_envs():
+                        self._publish_apex_planes(int(e), int(self.local.n[e]))
                 else:
                     while len(self.local) >= cfg.actor_batch:
                         self._publish_r2d2() if self.is_r2d2 else self._publish_apex()

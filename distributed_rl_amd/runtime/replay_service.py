@@ -33,6 +33,11 @@ def block_to_items(block) -> List:
         return [(block["state"][i].copy(), int(block["action"][i]), float(block["reward"][i]),
                  block["next_state"][i].copy(), float(block["done"][i])) for i in range(K)]
     K = block["action"].shape[0]
+    if block["kind"] == codec.KIND_R2D2_PLANES:                  # plane pool -> the per-step stacks the host PER stores
+        from ..algo.vec_assembly import stacks_from_planes
+        return [dict(frames=stacks_from_planes(block["planes"], block["win"][i]), action=block["action"][i].copy(),
+                     reward=block["reward"][i].copy(), done=block["done"][i].copy(), length=int(block["length"][i]),
+                     h0=block["h0"][i].copy(), c0=block["c0"][i].copy()) for i in range(K)]
     return [dict(frames=block["frames"][i].copy(), action=block["action"][i].copy(), reward=block["reward"][i].copy(),
                  done=block["done"][i].copy(), length=int(block["length"][i]), h0=block["h0"][i].copy(),
                  c0=block["c0"][i].copy()) for i in range(K)]

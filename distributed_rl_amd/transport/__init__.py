@@ -141,14 +141,7 @@ class ShmExperience(ExperienceChannel):
         self.n_slots = int(self._lib.drl_ring_n_slots(self._h))
 
     def push(self, block, kind, actor_id=0, env_steps=0):
-        if kind == codec.KIND_APEX:
-            need = codec.apex_block_bytes(block["action"].shape[0], tuple(block["state"].shape[1:]))
-        elif kind == codec.KIND_APEX_PLANES:
-            need = codec.apex_planes_block_bytes(block["action"].shape[0], block["planes"].shape[0],
-                                                 tuple(block["planes"].shape[1:]) + (4,))
-        else:
-            need = codec.r2d2_block_bytes(block["action"].shape[0], block["action"].shape[1], block["h0"].shape[1],
-                                          tuple(block["frames"].shape[2:]))
+        need = codec.block_bytes(block, kind)
         if need > self.slot_bytes:
             raise ValueError("experience block of %d bytes exceeds the ring slot size %d" % (need, self.slot_bytes))
         ticket = ctypes.c_uint64()

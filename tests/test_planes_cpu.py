@@ -130,3 +130,35 @@ def test_plane_block_wire_format_roundtrip_and_host_replay_items():
     for i, (s, a, r, s2, d) in enumerate(items):
         assert np.array_equal(s, out.state[i]) and np.array_equal(s2, out.next_state[i])
         assert a == int(out.action[i]) and r == pytest.approx(float(out.reward[i])) and d == float(out.done[i])
+
+
+def test_actor_with_a_non_shifting_env_publishes_short_blocks_instead_of_losing_them(run_id):
+    """``SyntheticRandom-v0`` restarts the stack on every observation (8 planes per env step), so a
+    default ``actor_batch`` of 50 transitions would span more planes than the actor's PlaneLog holds. The actor publishes
+    such an env early, as shorter blocks; nothing is dropped and every published window is the stack the env showed."""
+    from distributed_rl_amd import envs
+    from distributed_rl_amd.config import make_config
+    from distributed_rl_amd.models import DuelingDQN
+    from distributed_rl_amd.runtime.actor import Actor
+    from distributed_rl_amd.transport import connect
+    cfg = make_config("ape_x")                                    # defaults: actor_batch 50, nstep 3
+    exp, par = connect("inproc", run_id, create=True)
+    env = envs.make_vec("SyntheticRandom-v0", 2, seed=0)
+    shown = []
+    step0 = env.step
+
+    def spy(a):                                                   # record every observation the env ever delivers
+        out = step0(a)
+        shown.append(out[0].copy())
+        return out
+    env.step = spy
+    actor = Actor(1, env, DuelingDQN(env.n_action), cfg, exp, par, None, 1, seed=0)
+    actor.run(max_steps=120)
+    assert actor.published_blocks > 0 and actor.dropped_blocks == 0 and actor.lost_to_plane_log == 0
+    blocks = exp.drain()
+    sizes = [int(b["action"].shape[0]) for b in blocks]
+    assert sum(sizes) >= 2 * (120 - cfg.actor_batch) and max(sizes) < cfg.actor_batch          # short blocks, nearly every step
+    seen = {o[e].tobytes() for o in shown for e in range(2)}
+    for b in blocks:
+        for w in b["win_s2"]:                                     # s' of every transition is a stack the env really showed
+            assert np.ascontiguousarray(np.transpose(b["planes"][w:w + 4], (1, 2, 0))).tobytes() in seen

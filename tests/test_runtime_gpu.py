@@ -134,7 +134,11 @@ def test_hip_learner_r2d2_end_to_end(tmp_path, run_id):
     l2 = HipLearner("r2d2", 4, cfg, exp2, par2, None, replay_size=64, device="cuda")
     assert l2.resume(str(tmp_path / "model_4.pth")) == 4 and len(l2.replay) == n >= 10
     r2 = l2.replay
-    assert torch.equal(r2.frames.view(64, r2.P, -1)[:n].cpu(), snap["planes"]) and torch.equal(r2.length[:n].cpu(), snap["length"])
+    m_tot = int(snap["M"].sum())
+    assert int(snap["K"].sum()) == n and m_tot < n * r2.P                          # neighbouring sequences share planes
+    assert torch.equal(r2.frames[:m_tot].cpu(), snap["planes"]) and torch.equal(r2.length[:n].cpu(), snap["length"])
+    live = learner.replay.gather_stacks(torch.arange(n, device="cuda")).cpu()       # same observations through both stores
+    assert torch.equal(r2.gather_stacks(torch.arange(n, device="cuda")).cpu(), live)
     torch.testing.assert_close(r2.h0[:n].cpu(), snap["h0"])
     torch.testing.assert_close(r2.tree[:n].cpu(), snap["prio"])
     l2.close()
@@ -216,7 +220,8 @@ def test_r2d2_runtime_actor_with_engine_publishes_sequences(run_id):
     blocks = exp.drain()
     assert len(blocks) > 0
     b = blocks[0]
-    assert b["frames"].shape[1:] == (cfg.total_len, 84, 84, 4) and b["h0"].shape[1] == 512
+    assert b["kind"] == codec.KIND_R2D2_PLANES and b["win"].shape == (b["action"].shape[0], cfg.total_len) and b["h0"].shape[1] == 512
+    assert b["planes"].shape[0] < b["action"].shape[0] * (cfg.total_len + 3)       # consecutive sequences share their planes
     assert np.isfinite(b["prio"]).all() and (b["prio"] >= 0).all()
 
 
