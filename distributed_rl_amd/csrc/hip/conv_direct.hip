@@ -10,6 +10,7 @@
 // (conv2 / conv3 had the same form with the weights in LDS; 21.3 / 16.5 us at 1024 frames against 17.0 / 13.4 us for the
 // LDS-tiled implicit GEMM, and the LDS-halo kernels of conv_halo.hip beat both: it is gone.)
 #include "common.h"
+#include "conv_frag.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
@@ -44,30 +45,6 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
 #define DRL_CONV1_WAVES_PER_CU 8     // wave slots the tiles are dealt to (per CU): fewer waves = fewer weight set-ups
 #endif
 static int g_conv1_waves = DRL_CONV1_WAVES_PER_CU;   // host side; drl_conv1_set_waves: tuning hook
-typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma16h(uint4 a, uint4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), c, 0, 0, 0);
-}
-// 8 u8 -> 8 f16 holding 1024 + pixel: 4 x v_perm_b32
-__device__ __forceinline__ uint4 u8x8_to_f16_biased(uint2 v) {
-    const uint32_t k = 0x64646464u;
-    return make_uint4(__builtin_amdgcn_perm(k, v.x, 0x04010400u), __builtin_amdgcn_perm(k, v.x, 0x04030402u),
-                      __builtin_amdgcn_perm(k, v.y, 0x04010400u), __builtin_amdgcn_perm(k, v.y, 0x04030402u));
-}
-// 8 bf16 -> 8 f16, and the sum of the 8 values as the MFMA will see them
-__device__ __forceinline__ uint4 bf16x8_to_f16(bf16x8 v, float& sum) {
-    typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = bf2f((bf16_t)v[2 * i]), b = bf2f((bf16_t)v[2 * i + 1]);
-        const h2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
-        sum += (float)h[0] + (float)h[1];
-        o[i] = __builtin_bit_cast(uint32_t, h);
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // conv1: u8 frames -> bf16 [n,20,20,32]. Two input forms:
 //   dense (OFF = false):  [n,84,84,4] HWC stacks as the environments deliver them (actors); weights [32][kh][kw][c].

@@ -30,6 +30,7 @@
 // weights come from a tiny pre-pass (k_halo_wprep, once per optimizer step) and the epilogue multiplies with the ReLU mask
 // of the layer's input activation instead of adding a bias.
 #include "common.h"
+#include "conv_frag.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 halo_bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a VECTOR, not HIP's struct uint4: struct copies become memcpy and pin the array in scratch
@@ -51,31 +52,7 @@ struct HaloNet {
 
 enum { HALO_FWD = 0, HALO_DGRAD = 1, HALO_DGRAD_S2 = 2 };
 
-// Weight pre-pass of the input-gradient kernels (MODE 1 / 2), once per optimizer step:
-//   wt3[ci][a][b][co] = w3[co][2 - a][2 - b][ci]                                            (64 x 576)
-//   wt2[py * 2 + px][ci][a][b][co] = w2[co][py + 2 (1 - a)][px + 2 (1 - b)][ci]              (4 x 32 x 256)
-// It rides along in the conv2 FORWARD launch of the training step (extra workgroups behind the convolution's: a launch
-// of its own costs more than the 140 KB it moves).
-struct HaloPrep {
-    const bf16_t* w2;
-    const bf16_t* w3;
-    bf16_t* wt2;
-    bf16_t* wt3;
-    int nblk;
-};
-constexpr int HALO_PREP_ELEMS = 64 * 576 + 4 * 32 * 256, HALO_PREP_BLOCKS = 34;      // 34 x 256 threads x 8 elements
-
-__device__ __forceinline__ void halo_wprep_elem(const HaloPrep& p, int i) {
-    if (i < 64 * 576) {
-        const int co = i & 63, b = (i >> 6) % 3, a = (i / 192) % 3, ci = i / 576;
-        p.wt3[i] = p.w3[((co * 3 + (2 - a)) * 3 + (2 - b)) * 64 + ci];
-    } else if (i < HALO_PREP_ELEMS) {
-        const int j = i - 64 * 576;
-        const int co = j & 63, b = (j >> 6) & 1, a = (j >> 7) & 1, ci = (j >> 8) & 31, cls = j >> 13, py = cls >> 1, px = cls & 1;
-        p.wt2[j] = p.w2[((co * 4 + py + 2 * (1 - a)) * 4 + px + 2 * (1 - b)) * 32 + ci];
-    }
-}
-
+// (weight pre-pass of the input-gradient kernels: HaloPrep / halo_wprep_elem, conv_frag.h)
 // SH x SW x CI: source frame; PAD: zero border of the LDS image; P / RP / FP: pixel, row and frame pitch of the image in
 // 16-byte slots. F frames per group, TC tiles per wave pass.
 template <int SH, int SW, int CI, int PAD, int KS, int S, int P, int RP, int FP, int F, int TC, int OCC, int MODE>

@@ -1,0 +1,345 @@
+// Fused forward of the Nature-CNN torso on gfx950 (SURVEY G1-G3 as ONE kernel; VERDICT r2 "do this" #2):
+//   u8 planes / stacks -> conv1 + ReLU -> conv2 + ReLU -> conv3 + ReLU -> act3 [n, 7, 7, 64] bf16,
+// with act1 (25.6 KB / frame) and act2 (10.4 KB / frame) living in LDS. They are written to HBM only for the frames a
+// backward pass will read (a per-network frame range): the Ape-X learner needs them for B of its 3 B forwards, R2D2 for the
+// learning window of the online network only.
+//
+// Why one kernel: at the learner's batch (1536 frame-forwards on 256 CUs = 6 frames per CU) the three per-layer launches
+// are fixed cost: 27 + 17.4 + 15.9 us where their steady-state rates (R2D2, 60 frames per CU) would need 18 us. Each launch
+// pays its own ramp (weights -> registers, first frame group through an empty pipeline) and tail, and layer l + 1 cannot
+// start before the slowest workgroup of layer l has finished.
+//
+// Structure: persistent 512-thread workgroups, one per CU, one FRAME per round, two roles (by wave number >= 4, the two
+// waves of a SIMD get complementary work - MI355X_MICROARCH "two waves per SIMD" item 9):
+//   waves 0-3 "P": conv1 exactly as conv_direct.hip does it (u8 fragments global -> VGPR in MFMA layout, biased-f16 trick,
+//               all 32 x 256 weights in 64 VGPRs) - but the 16-byte result goes to the LDS image conv2 reads. The 25 output
+//               tiles of a frame are dealt round-robin to the four waves (7 slots each, slot 6 of waves 1-3 repeats tile 24);
+//               slot j's input registers are re-loaded with the NEXT frame's slot j as soon as they are consumed, so every
+//               global load has one whole frame period (> 1 us) to land and nothing is waited for.
+//   waves 4-7 "C": conv2 then conv3 as conv_halo.hip does them (fragments by ds_read_b128 with the tap as the instruction's
+//               immediate, weights in registers, conflict-free padded images), each wave owning 16 of the 64 output
+//               channels of BOTH layers: 64 + 72 weight VGPRs. (The two-MFMAs-per-fragment form of conv_halo.hip - 32
+//               channels per wave - needs 128 + 144 and does not fit next to a second wave on the SIMD.)
+// Round i, two workgroup barriers:
+//   segment A:  P: conv1 tiles 0..15 of frame i+1 -> image1[(i+1) & 1]      C: conv2 of frame i: image1[i & 1] -> image2
+//   segment B:  P: conv1 tiles 16..24 of frame i+1                          C: conv3 of frame i: image2 -> act3 (HBM)
+// P's global loads stay in flight across the barriers (raw s_barrier behind an lgkmcnt-only wait).
+// LDS: 2 x 32 320 (act1 images, pixel pitch 80 B, row pitch 101 slots) + 14 752 (act2 image, pixel pitch 160 B, row pitch
+// 102 slots) = 79 392 B: the layouts of conv_halo.hip (scripts/debug/halo_lds_layout.py).
+#include "common.h"
+#include "conv_frag.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 torso_bf16x8;
+__device__ __forceinline__ f32x4 torso_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(torso_bf16x8, a), __builtin_bit_cast(torso_bf16x8, b), c, 0, 0, 0);
+}
+
+struct TorsoNet {
+    const long long* frame_off;     // plane store: byte offset of every frame's first plane (null: dense HWC stacks)
+    const bf16_t *w1, *w2, *w3;     // conv1 [32][256] (k order of the input form, conv_direct.hip), conv2 [64][4][4][32], conv3 [64][3][3][64]
+    const float *b1, *b2, *b3;
+    bf16_t *act1, *act2, *act3;     // [frames][20][20][32], [frames][9][9][64] (rows [save_lo, save_hi) written), [frames][7][7][64]
+    int frames, save_lo, save_hi, nblk;
+};
+
+constexpr int T_P1 = 5, T_RP1 = 101, T_IMG1 = 2020 * 16;     // conv2's input image: slots of 16 bytes
+constexpr int T_P2 = 10, T_RP2 = 102, T_IMG2 = 922 * 16;     // conv3's input image
+constexpr int T_LDS = 2 * T_IMG1 + T_IMG2;
+
+// every LDS access of this wave has completed, then the workgroup barrier; vector-memory operations stay in flight
+__device__ __forceinline__ void torso_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <bool OFF>
+__global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict__ x, TorsoNet n1, TorsoNet n2, HaloPrep prep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // image1[0], image1[1], image2
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    if ((int)blockIdx.x >= n1.nblk + n2.nblk) {                         // the weight pre-pass workgroups (conv_frag.h)
+        const int b = (int)blockIdx.x - n1.nblk - n2.nblk;
+        for (int i = b * 512 + tid; i < HALO_PREP_ELEMS; i += prep.nblk * 512) halo_wprep_elem(prep, i);
+        return;
+    }
+    const bool second = (int)blockIdx.x >= n1.nblk;                     // block-uniform
+    const int frames = second ? n2.frames : n1.frames, nblk = second ? n2.nblk : n1.nblk;
+    const int save_lo = second ? n2.save_lo : n1.save_lo, save_hi = second ? n2.save_hi : n1.save_hi;
+    const int blk = second ? (int)blockIdx.x - n1.nblk : (int)blockIdx.x;
+    const int nf = (frames - blk + nblk - 1) / nblk;                    // frames blk, blk + nblk, ...
+    if (nf <= 0) return;                                                // block-uniform, before any barrier
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (wave < 4) {
+        // ------------------------------------------------ P: conv1 ------------------------------------------------
+        const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
+        const bf16_t* __restrict__ w = second ? n2.w1 : n1.w1;
+        const float* __restrict__ bias = second ? n2.b1 : n1.b1;
+        bf16_t* __restrict__ act1 = second ? n2.act1 : n1.act1;
+        uint4 wf[2][8];
+        float acc0[2][4];                           // accumulator start: -1024 * (sum over k of this lane's channels' weights)
+        {
+            float csum[2] = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    wf[t][s] = bf16x8_to_f16(*reinterpret_cast<const bf16x8*>(w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8),
+                                             csum[t]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {           // lanes r, r+16, r+32, r+48 hold the four k-quarters of MFMA row r
+                csum[t] += __shfl_xor(csum[t], 16, WAVE);
+                csum[t] += __shfl_xor(csum[t], 32, WAVE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc0[t][i] = -1024.0f * __shfl(csum[t], g * 4 + i, WAVE);   // accumulator row g*4+i
+            }
+        }
+        float4 b4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
+        // slot j of this wave = output tile min(wave + 4 j, 24): byte offset of the lane's first fragment inside a frame,
+        // of its 16-byte result inside an act1 image, and inside a frame of the act1 array
+        int pofs[7], lofs[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int m = min(wave + 4 * j, 24) * 16 + r, oy = m / 20, ox = m - oy * 20;
+            pofs[j] = OFF ? (4 * oy + g) * 84 + 4 * ox : oy * (4 * 336) + ox * 16 + g * 8;
+            lofs[j] = (oy * T_RP1 + ox * T_P1 + g) * 16;
+        }
+        const int gofs0 = (wave * 16 + r) * 64 + g * 16, gofs6 = (24 * 16 + r) * 64 + g * 16;   // slot j: pixel m0 + 64 j; slot 6: tile 24
+        auto koff = [](int s) -> int { return OFF ? (s >> 1) * 7056 + (s & 1) * 336 : s * 336; };
+        auto frame_of = [&](int i) -> int { return blk + min(i, nf - 1) * nblk; };          // wave-uniform
+        // the frame's base is a SCALAR load (constant address space: the list is read-only for the launch); as a vector
+        // load its wait would drain the whole prefetch (vmcnt counts in order)
+        typedef const long long __attribute__((address_space(4)))* const_ll_ptr;
+        auto fbase = [&](int f) -> long long {
+            if constexpr (OFF) return ((const_ll_ptr)frame_off)[f];
+            else return (long long)f * 28224;
+        };
+        uint2 buf[7][8];
+        auto issue = [&](uint2 (&b)[8], long long fb, int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const uint2*>(x + fb + pofs[j] + koff(s));
+        };
+        // one slot: 16 MFMAs, bias + ReLU, 16 bytes into the image (and into HBM where a backward will read them); then the
+        // slot's registers are re-loaded with the same slot of the next frame
+        auto slot = [&](int j, unsigned img, int frame, long long fb_next) __attribute__((always_inline)) {
+            f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const uint4 xf = u8x8_to_f16_biased(buf[j][s]);
+                acc[0] = mfma16h(wf[0][s], xf, acc[0]);
+                acc[1] = mfma16h(wf[1][s], xf, acc[1]);
+            }
+            issue(buf[j], fb_next, j);
+            constexpr float SC = 1.0f / 255.0f;          // pixel normalisation x/255 folded into the epilogue
+            uint32_t o[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                o[2 * t] = pack_bf2(fmaxf(acc[t][0] * SC + b4[t].x, 0.f), fmaxf(acc[t][1] * SC + b4[t].y, 0.f));
+                o[2 * t + 1] = pack_bf2(fmaxf(acc[t][2] * SC + b4[t].z, 0.f), fmaxf(acc[t][3] * SC + b4[t].w, 0.f));
+            }
+            const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(smem + img + lofs[j]) = ov;
+            if (frame >= save_lo && frame < save_hi)     // wave-uniform
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(act1) + (long long)frame * 25600 + (j < 6 ? gofs0 + 4096 * j : gofs6)) = ov;
+        };
+        {
+            const long long fb0 = fbase(frame_of(0));
+#pragma unroll
+            for (int j = 0; j < 7; ++j) issue(buf[j], fb0, j);
+        }
+        {                                                // frame 0 -> image1[0], before the first round
+            const int f = frame_of(0);
+            const long long fbn = fbase(frame_of(1));
+#pragma unroll
+            for (int j = 0; j < 7; ++j) slot(j, 0u, f, fbn);
+        }
+        torso_barrier();
+        for (int i = 0; i < nf; ++i) {
+            // in the last round this is the last frame once more (same values to the same places): no branch in the loop
+            const int f = frame_of(i + 1);
+            const long long fbn = fbase(frame_of(i + 2));
+            const unsigned img = ((i + 1) & 1) * T_IMG1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slot(j, img, f, fbn);
+            torso_barrier();
+#pragma unroll
+            for (int j = 4; j < 7; ++j) slot(j, img, f, fbn);
+            torso_barrier();
+        }
+    } else {
+        // ------------------------------------------- C: conv2, conv3 ----------------------------------------------
+        const int c = wave - 4;                                          // output channels [16 c, 16 c + 16) of both layers
+        const bf16_t* __restrict__ w2 = second ? n2.w2 : n1.w2;
+        const bf16_t* __restrict__ w3 = second ? n2.w3 : n1.w3;
+        const float* __restrict__ bias2 = second ? n2.b2 : n1.b2;
+        const float* __restrict__ bias3 = second ? n2.b3 : n1.b3;
+        bf16_t* __restrict__ act2 = second ? n2.act2 : n1.act2;
+        bf16_t* __restrict__ act3 = second ? n2.act3 : n1.act3;
+        bf16x8 wf2[16], wf3[18];                    // A operand: lane supplies W[channel 16 c + l % 16][k-step s, k = (l / 16) * 8 ..]
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wf2[s] = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(16 * c + r) * 512 + s * 32 + g * 8);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) wf3[s] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(16 * c + r) * 576 + s * 32 + g * 8);
+        // the lane ends up with channels 16 c + 4 g .. + 3 of pixel r of every tile
+        float4 bb2 = *reinterpret_cast<const float4*>(bias2 + 16 * c + 4 * g);
+        float4 bb3 = *reinterpret_cast<const float4*>(bias3 + 16 * c + 4 * g);
+        // rows past the last pixel are computed from the last pixel's inputs and store the same values to the same place
+        unsigned xb2[6], wo2[6], go2[6], xb3[4], go3[4];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int m = min(u * 16 + r, 80), oy = m / 9, ox = m - oy * 9;
+            xb2[u] = (unsigned)((2 * oy) * T_RP1 + (2 * ox) * T_P1 + g) * 16u;
+            wo2[u] = 2u * T_IMG1 + (unsigned)(oy * T_RP2 + ox * T_P2) * 16u + (unsigned)(32 * c + 8 * g);
+            go2[u] = (unsigned)(m * 128 + 32 * c + 8 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = min(u * 16 + r, 48), oy = m / 7, ox = m - oy * 7;
+            xb3[u] = 2u * T_IMG1 + (unsigned)(oy * T_RP2 + ox * T_P2 + g) * 16u;
+            go3[u] = (unsigned)(m * 128 + 32 * c + 8 * g);
+        }
+        // land weights and biases once, here (left to the compiler the waits sit inside the round loop)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(wf2[s]));
+#pragma unroll
+        for (int s = 0; s < 18; ++s) asm volatile("" : "+v"(wf3[s]));
+        asm volatile("" : "+v"(bb2.x), "+v"(bb2.y), "+v"(bb2.z), "+v"(bb2.w), "+v"(bb3.x), "+v"(bb3.y), "+v"(bb3.z), "+v"(bb3.w));
+        __builtin_amdgcn_s_setprio(1);              // the second-dispatched half loses every arbitration otherwise
+        torso_barrier();                            // frame 0 is in image1[0]
+        for (int i = 0; i < nf; ++i) {
+            const int frame = blk + i * nblk;
+            const unsigned cur = (i & 1) * T_IMG1;
+            {   // ---- conv2: 6 tiles x 16 k-steps (k-step = one tap of the 4x4 kernel x 32 channels) ----
+                f32x4 acc[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 xf[2][6];
+                auto rd = [&](bf16x8 (&dst)[6], int s) __attribute__((always_inline)) {
+                    const int off = ((s >> 2) * T_RP1 + (s & 3) * T_P1) * 16;       // immediate offset of the ds_read
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) dst[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb2[u] + off);
+                };
+                rd(xf[0], 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s + 1 < 16) {
+                        rd(xf[(s + 1) & 1], s + 1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // 6 ds reads of k-step s + 1 ...
+                    }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) acc[u] = torso_mfma(wf2[s], xf[s & 1][u], acc[u]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);              // ... then the 6 MFMAs of k-step s
+                }
+                const bool save = frame >= save_lo && frame < save_hi;              // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const uint2 o = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb2.x, 0.f), fmaxf(acc[u][1] + bb2.y, 0.f)),
+                                               pack_bf2(fmaxf(acc[u][2] + bb2.z, 0.f), fmaxf(acc[u][3] + bb2.w, 0.f)));
+                    *reinterpret_cast<uint2*>(smem + wo2[u]) = o;
+                    if (save) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(act2) + (long long)frame * 10368 + go2[u]) = o;
+                }
+            }
+            torso_barrier();
+            {   // ---- conv3: 4 tiles x 18 k-steps (k-step = half the 64 channels of one tap of the 3x3 kernel) ----
+                f32x4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 xf[2][4];
+                auto rd = [&](bf16x8 (&dst)[4], int s) __attribute__((always_inline)) {
+                    const int tap = s >> 1, ky = tap / 3, kx = tap - ky * 3;
+                    const int off = (ky * T_RP2 + kx * T_P2 + (s & 1) * 4) * 16;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const bf16x8*>(smem + xb3[u] + off);
+                };
+                rd(xf[0], 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int s = 0; s < 18; ++s) {
+                    if (s + 1 < 18) {
+                        rd(xf[(s + 1) & 1], s + 1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = torso_mfma(wf3[s], xf[s & 1][u], acc[u]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint2 o = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb3.x, 0.f), fmaxf(acc[u][1] + bb3.y, 0.f)),
+                                               pack_bf2(fmaxf(acc[u][2] + bb3.z, 0.f), fmaxf(acc[u][3] + bb3.w, 0.f)));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(act3) + (long long)frame * 6272 + go3[u]) = o;
+                }
+            }
+            torso_barrier();
+        }
+    }
+}
+
+// CUs that a concurrently running persistent kernel of another stream occupies (conv_halo.hip: drl_halo_set_busy). A torso
+// workgroup fills a CU's registers: it cannot share one, so the grid leaves those CUs out.
+static int g_torso_busy_cus = 0;
+DRL_API int drl_torso_set_busy(int cus) {
+    if (cus < 0 || cus > 192) return -1;
+    g_torso_busy_cus = cus;
+    return 0;
+}
+
+// One launch: the torso of network 1 over frames1 frames and (frames2 > 0) of network 2 over frames2 frames of the same
+// store x. off = null: dense HWC u8 stacks [n, 84, 84, 4] (conv1 weights in HWC order); else byte offsets into a plane store
+// (conv1 weights in (c, kh, kw) order). save range [lo, hi): frames whose act1 / act2 are also written to HBM.
+// prep_wt2 != null: extra workgroups write the flipped / transposed conv2 / conv3 weights of the input-gradient kernels.
+DRL_API int drl_torso_fwd(const void* x,
+                          const long long* off1, int frames1, const void* const* w1, const float* const* b1, void* const* act1,
+                          int save_lo1, int save_hi1,
+                          const long long* off2, int frames2, const void* const* w2, const float* const* b2, void* const* act2,
+                          int save_lo2, int save_hi2,
+                          const void* prep_w2, const void* prep_w3, void* prep_wt2, void* prep_wt3, hipStream_t s) {
+    if (frames1 <= 0 || frames2 < 0 || !x) return -1;
+    if ((off1 == nullptr) != (frames2 > 0 ? off2 == nullptr : off1 == nullptr)) return -1;      // one input form per launch
+    auto net = [](const long long* off, int frames, const void* const* w, const float* const* b, void* const* a, int lo, int hi) {
+        TorsoNet n{};
+        if (frames <= 0) return n;
+        n.frame_off = off;
+        n.w1 = (const bf16_t*)w[0]; n.w2 = (const bf16_t*)w[1]; n.w3 = (const bf16_t*)w[2];
+        n.b1 = b[0]; n.b2 = b[1]; n.b3 = b[2];
+        n.act1 = (bf16_t*)a[0]; n.act2 = (bf16_t*)a[1]; n.act3 = (bf16_t*)a[2];
+        n.frames = frames;
+        n.save_lo = lo < 0 ? 0 : lo;
+        n.save_hi = hi > frames ? frames : hi;
+        if (!n.act1 || !n.act2) n.save_lo = n.save_hi = 0;
+        return n;
+    };
+    TorsoNet n1 = net(off1, frames1, w1, b1, act1, save_lo1, save_hi1);
+    TorsoNet n2 = net(off2, frames2, frames2 > 0 ? w2 : nullptr, frames2 > 0 ? b2 : nullptr, frames2 > 0 ? act2 : nullptr, save_lo2, save_hi2);
+    if (!n1.w1 || !n1.w2 || !n1.w3 || !n1.b1 || !n1.b2 || !n1.b3 || !n1.act3) return -1;
+    if (frames2 > 0 && (!n2.w1 || !n2.w2 || !n2.w3 || !n2.b1 || !n2.b2 || !n2.b3 || !n2.act3)) return -1;
+    HaloPrep prep{(const bf16_t*)prep_w2, (const bf16_t*)prep_w3, (bf16_t*)prep_wt2, (bf16_t*)prep_wt3, prep_wt2 ? HALO_PREP_BLOCKS / 2 : 0};
+    if (prep.nblk && (!prep_w2 || !prep_w3 || !prep_wt3)) return -1;
+    // persistent workgroups, one per free CU, dealt to the two networks in proportion to their frames; equal rounds per
+    // workgroup of a network (ceil(frames / rounds) workgroups do the same work in the same number of rounds)
+    const int slots = 256 - g_torso_busy_cus;
+    int b1n, b2n = 0;
+    if (frames1 + frames2 <= slots) { b1n = frames1; b2n = frames2; }
+    else if (frames2 == 0) b1n = slots;
+    else {
+        b1n = (int)((long long)slots * frames1 / (frames1 + frames2));
+        b1n = b1n < 1 ? 1 : (b1n > slots - 1 ? slots - 1 : b1n);
+        b2n = slots - b1n;
+    }
+    auto even = [](int frames, int blocks) { const int rounds = (frames + blocks - 1) / blocks; return (frames + rounds - 1) / rounds; };
+    n1.nblk = even(frames1, b1n);
+    n2.nblk = frames2 > 0 ? even(frames2, b2n) : 0;
+    const int grid = n1.nblk + n2.nblk + prep.nblk;
+    if (off1) {
+        static bool once = ((void)hipFuncSetAttribute((const void*)k_torso_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS), true);
+        (void)once;
+        k_torso_fwd<true><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute((const void*)k_torso_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS), true);
+        (void)once;
+        k_torso_fwd<false><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep);
+    }
+    return (int)hipGetLastError();
+}

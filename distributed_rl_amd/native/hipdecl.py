@@ -44,6 +44,9 @@ SIGS = {
     "drl_conv_halo_wprep": [P, P, P, P, P],
     "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
     "drl_halo_set_busy": [I, I],
+    # conv_torso.hip
+    "drl_torso_fwd": [P, P, I, P, P, P, I, I, P, I, P, P, P, I, I, P, P, P, P, P],
+    "drl_torso_set_busy": [I],
     # conv_wgrad_halo.hip
     "drl_conv_wgrad_halo": [I, P, P, P, P, P, I, I, P],
     "drl_conv1_wgrad_halo": [P, P, P, P, P, P, I, I, P],

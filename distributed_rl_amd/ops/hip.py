@@ -407,6 +407,56 @@ def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w
                                        _p(pw2), _p(pw3), _p(pwt2), _p(pwt3), _s()), "conv_halo_fwd")
 
 
+class TorsoNet:
+    """One network's operands of the fused torso forward (``torso_fwd``): plane-store byte offsets (None = dense HWC
+    stacks), frame count, the three conv weights (bf16; conv1 in the input form's k order) and biases (fp32), act3 out,
+    and - only where a backward pass will read them - act1 / act2 arrays + the frame range ``save`` to write."""
+
+    def __init__(self, frame_off, frames: int, w, b, act3, act1=None, act2=None, save=(0, 0)):
+        assert len(w) == 3 and len(b) == 3
+        for t, n in zip(w, (32 * 256, 64 * 512, 64 * 576)):
+            _chk(t, torch.bfloat16, "w"); assert t.numel() == n
+        for t, n in zip(b, (32, 64, 64)):
+            _chk(t, torch.float32, "bias"); assert t.numel() == n
+        _chk(act3, torch.bfloat16, "act3"); assert act3.numel() >= frames * 3136
+        lo, hi = save
+        if hi > lo:
+            _chk(act1, torch.bfloat16, "act1"); _chk(act2, torch.bfloat16, "act2")
+            assert 0 <= lo and hi <= frames and act1.numel() >= hi * 12800 and act2.numel() >= hi * 5184
+        if frame_off is not None:
+            _chk(frame_off, torch.int64, "frame_off"); assert frame_off.numel() >= frames
+        self.frame_off, self.frames, self.save = frame_off, int(frames), (int(lo), int(hi))
+        self._keep = (w, b, act1, act2, act3)
+        self.w = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in w])
+        self.b = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in b])
+        self.a = (ctypes.c_void_p * 3)(act1.data_ptr() if hi > lo else None, act2.data_ptr() if hi > lo else None, act3.data_ptr())
+
+
+def torso_fwd(x: torch.Tensor, net1: TorsoNet, net2: Optional[TorsoNet] = None, prep=None) -> None:
+    """conv1 -> conv2 -> conv3 (+bias+ReLU each) of one or two networks over frames of ``x`` as ONE launch (conv_torso.hip):
+    act1 / act2 live in LDS and reach HBM only for each network's ``save`` range. prep = (w2, w3, wt2, wt3): as
+    ``conv_halo_fwd``."""
+    _chk(x, torch.uint8, "x")
+    if net2 is not None:
+        assert (net1.frame_off is None) == (net2.frame_off is None)
+    if net1.frame_off is None:
+        assert x.numel() >= max(net1.frames, net2.frames if net2 else 0) * 28224
+    pw2, pw3, pwt2, pwt3 = prep if prep is not None else (None, None, None, None)
+    if prep is not None:
+        for t, n in ((pw2, 64 * 512), (pw3, 64 * 576), (pwt2, 64 * 512), (pwt3, 64 * 576)):
+            _chk(t, torch.bfloat16, "prep"); assert t.numel() == n
+    n2 = net2
+    _ck(native.hip().drl_torso_fwd(_p(x), _p(net1.frame_off), net1.frames, net1.w, net1.b, net1.a, net1.save[0], net1.save[1],
+                                   _p(n2.frame_off) if n2 else None, n2.frames if n2 else 0, n2.w if n2 else None,
+                                   n2.b if n2 else None, n2.a if n2 else None, n2.save[0] if n2 else 0, n2.save[1] if n2 else 0,
+                                   _p(pw2), _p(pw3), _p(pwt2), _p(pwt3), _s()), "torso_fwd")
+
+
+def torso_set_busy(cus: int) -> None:
+    """CUs a concurrently running persistent kernel of another stream occupies: the fused torso leaves them out of its grid."""
+    _ck(native.hip().drl_torso_set_busy(int(cus)), "torso_set_busy")
+
+
 def conv_halo_wprep(w2: torch.Tensor, w3: torch.Tensor, wt2: torch.Tensor, wt3: torch.Tensor) -> None:
     """Flipped / transposed copies of the conv2 and conv3 weights for the LDS-halo input-gradient kernels (one tiny launch;
     the learners run it once per optimizer step): wt2 bf16 [4, 32, 2, 2, 64], wt3 bf16 [64, 3, 3, 64]."""

@@ -273,8 +273,9 @@ def test_r2d2_engine_step_matches_oracle():
     td.loss.backward()
     with torch.no_grad():
         q_ref, _ = model.unroll(frames, h0, c0, grad_from=T)
-    torch.testing.assert_close(eng.on.q.view(T, B, -1).cpu(), q_ref, rtol=5e-2, atol=5e-2)
-    torch.testing.assert_close(eng.tg.q.view(T, B, -1).cpu(), q_ref, rtol=5e-2, atol=5e-2)
+    # relative to the largest |Q| (random-init Q values are ~0.05: an absolute tolerance of that size cannot fail)
+    for q_eng in (eng.on.q, eng.tg.q):
+        assert float((q_eng.view(T, B, -1).cpu() - q_ref).abs().max()) <= 2e-2 * float(q_ref.abs().max())
     assert st["loss"] == pytest.approx(float(td.loss.detach()), rel=8e-2, abs=5e-3)
     torch.testing.assert_close(eng.new_prio.cpu(), td.prio, rtol=1e-1, atol=3e-2)
     grads = eng.G.state_dict()

@@ -1016,3 +1016,88 @@ def test_gemm_big_two_problems_per_launch():
     torch.cuda.synchronize()
     torch.testing.assert_close(c, a.float() @ b.float().t() + bias, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(c2, a2.float() @ b2.float().t() + bias2, rtol=1e-4, atol=1e-4)
+
+
+# ---- fused torso forward (conv_torso.hip) ------------------------------------------------------------------------------
+def _torso_weights(seed):
+    """(w1 planes-order, w1 HWC-order, w2, w3), (b1, b2, b3) of one network."""
+    ws, bs = [], []
+    for layer in (1, 2, 3):
+        _, _, w, b, _ = _conv_setup(layer, 1, seed + layer)
+        ws.append(w); bs.append(b)
+    return (_w1_planes(ws[0]), ws[0], ws[1], ws[2]), bs
+
+
+def _three_launch_torso(H, x, off, frames, w1, w2, w3, bs):
+    a1 = torch.zeros(frames, 20, 20, 32, dtype=torch.bfloat16, device=DEV)
+    a2 = torch.zeros(frames, 9, 9, 64, dtype=torch.bfloat16, device=DEV)
+    a3 = torch.zeros(frames, 7, 7, 64, dtype=torch.bfloat16, device=DEV)
+    H.conv_fwd(1, x, w1, bs[0], a1, frames, frame_off=off)
+    H.conv_fwd(2, a1, w2, bs[1], a2, frames)
+    H.conv_fwd(3, a2, w3, bs[2], a3, frames)
+    return a1, a2, a3
+
+
+@pytest.mark.parametrize("f1,f2,save1", [(1, 0, (0, 1)), (5, 3, (1, 4)), (64, 0, (0, 0)), (300, 150, (0, 150)), (1024, 512, (0, 512)),
+                                         (1537, 700, (100, 1000))])
+def test_torso_fwd_fused_matches_three_launches(hip, f1, f2, save1):
+    """conv1 -> conv2 -> conv3 in one launch over a plane store, one and two networks, fewer / more frames than workgroups:
+    act3 is bit-identical to the three per-layer launches (same products in the same order), act1 / act2 are written
+    exactly for the save range (bit-identical there, untouched elsewhere), and the guard row behind act3 stays untouched."""
+    H = hip
+    n = f1 + f2
+    store = torch.randint(0, 256, (4 * (n + 7), 7056), dtype=torch.uint8).to(DEV)              # a plane store
+    off = (torch.randperm(4 * (n + 7) - 3)[:n] * 7056).to(DEV)                                 # any 4 consecutive planes
+    nets, refs = [], []
+    for k, (f, o, save) in enumerate(((f1, off[:f1], save1), (f2, off[f1:], (0, 0)))):
+        if f == 0:
+            nets.append(None)
+            continue
+        (w1p, _, w2, w3), bs = _torso_weights(50 + 10 * k)
+        w1p, w2, w3, bs = w1p.to(DEV), w2.to(DEV), w3.to(DEV), [b.to(DEV) for b in bs]
+        o = o.contiguous()
+        refs.append(_three_launch_torso(H, store, o, f, w1p, w2, w3, bs))
+        a1 = torch.full((f, 20, 20, 32), 7.0, dtype=torch.bfloat16, device=DEV)
+        a2 = torch.full((f, 9, 9, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+        a3 = torch.full((f + 1, 7, 7, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+        nets.append((H.TorsoNet(o, f, (w1p, w2, w3), bs, a3, a1, a2, save), a1, a2, a3, save))
+    H.torso_fwd(store, nets[0][0], nets[1][0] if nets[1] is not None else None)
+    torch.cuda.synchronize()
+    for net, ref in zip([x for x in nets if x is not None], refs):
+        _, a1, a2, a3, (lo, hi) = net
+        f = a1.shape[0]
+        assert torch.equal(a3[:f], ref[2]) and bool((a3[f] == 7.0).all())
+        for a, rf in ((a1, ref[0]), (a2, ref[1])):
+            assert torch.equal(a[lo:hi], rf[lo:hi])
+            assert bool((a[:lo] == 7.0).all()) and bool((a[hi:] == 7.0).all())
+    # next to a persistent kernel of another stream the grid leaves CUs out: other shares per workgroup, same bits
+    H.torso_set_busy(64)
+    try:
+        for net in nets:
+            if net is not None:
+                net[3][:-1].zero_()
+        H.torso_fwd(store, nets[0][0], nets[1][0] if nets[1] is not None else None)
+        torch.cuda.synchronize()
+    finally:
+        H.torso_set_busy(0)
+    for net, ref in zip([x for x in nets if x is not None], refs):
+        assert torch.equal(net[3][:-1], ref[2])
+
+
+def test_torso_fwd_fused_dense_stacks_and_weight_prepass(hip):
+    """Dense HWC u8 stacks (the actors' input form) through the fused kernel == the three launches; the extra workgroups
+    of the launch write the same flipped / transposed weights as conv_halo_wprep."""
+    H = hip
+    f = 70
+    x = torch.randint(0, 256, (f, 84, 84, 4), dtype=torch.uint8).to(DEV)
+    (_, w1, w2, w3), bs = _torso_weights(80)
+    w1, w2, w3, bs = w1.to(DEV), w2.to(DEV), w3.to(DEV), [b.to(DEV) for b in bs]
+    ref = _three_launch_torso(H, x, None, f, w1, w2, w3, bs)
+    a3 = torch.zeros(f, 7, 7, 64, dtype=torch.bfloat16, device=DEV)
+    wt2, wt3 = torch.zeros(4, 32, 2, 2, 64, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 3, 3, 64, dtype=torch.bfloat16, device=DEV)
+    H.torso_fwd(x, H.TorsoNet(None, f, (w1, w2, w3), bs, a3), prep=(w2, w3, wt2, wt3))
+    r2, r3 = torch.zeros_like(wt2), torch.zeros_like(wt3)
+    H.conv_halo_wprep(w2, w3, r2, r3)
+    torch.cuda.synchronize()
+    assert torch.equal(a3, ref[2])
+    assert torch.equal(wt2, r2) and torch.equal(wt3, r3)

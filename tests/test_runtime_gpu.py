@@ -49,7 +49,8 @@ def test_actor_engine_matches_module():
     eng.load_flat(ParamPack.from_module(m2).flat.numpy())
     eng.act(obs)
     with torch.no_grad():
-        torch.testing.assert_close(eng.q_values().cpu(), m2(torch.from_numpy(obs)), rtol=5e-2, atol=5e-2)
+        q_ref = m2(torch.from_numpy(obs))
+        assert float((eng.q_values().cpu() - q_ref).abs().max()) <= 2e-2 * float(q_ref.abs().max())
 
 
 def test_hip_learner_apex_end_to_end(tmp_path, run_id):
@@ -168,7 +169,7 @@ def test_r2d2_actor_engine_matches_module():
         a = eng.act(obs)
         with torch.no_grad():
             q = m(torch.from_numpy(obs))
-        torch.testing.assert_close(eng.q_values().cpu(), q, rtol=5e-2, atol=5e-2)
+        assert float((eng.q_values().cpu() - q).abs().max()) <= 2e-2 * float(q.abs().max())
         top2 = q.topk(2, 1).values
         clear = (top2[:, 0] - top2[:, 1]) > 0.1
         assert (torch.from_numpy(a)[clear] == q.argmax(1)[clear]).all()
