@@ -47,15 +47,32 @@ class TorsoBuffers:
         self.q = torch.zeros(n, n_action, device=device)
 
 
+def torso_net(cache: dict, frame_off: Optional[torch.Tensor], n: int, wb: ParamPack, wf: ParamPack, act1, act2, act3,
+              save=(0, 0), w1=None) -> "H.TorsoNet":
+    """The fused torso kernel's operand block for one network (ops.hip.TorsoNet), built once per distinct set of buffers:
+    ``cache`` (any dict that lives as long as the buffers) is keyed by the addresses involved."""
+    key = (frame_off.data_ptr() if frame_off is not None else 0, n, wb.flat.data_ptr(), wf.flat.data_ptr(), act3.data_ptr(),
+           act1.data_ptr() if act1 is not None else 0, tuple(save), w1.data_ptr() if w1 is not None else 0)
+    net = cache.get(key)
+    if net is None:
+        net = cache[key] = H.TorsoNet(frame_off, n, (w1 if w1 is not None else wb.view("conv1.w"), wb.view("conv2.w"), wb.view("conv3.w")),
+                                      (wf.view("conv1.b"), wf.view("conv2.b"), wf.view("conv3.b")), act3, act1, act2, save)
+    return net
+
+
 def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int, wb: ParamPack, wf: ParamPack,
                   buf: TorsoBuffers, action_out=None, eps=None, eps_mod: int = 0, seed: int = 0, ctr=None, w1=None) -> None:
-    """wb = bf16 weights, wf = fp32 params (biases). 5 launches: conv1-3, FC1(+bias+ReLU), head(+dueling[+ε-greedy]).
-    frame_off given: x_u8 is a replay store of single planes and conv1 uses the pack's (c, kh, kw) weights; dense HWC
-    stacks (actors, frame_off None) need ``w1`` = the HWC-ordered copy (models.packing.conv1_hwc)."""
+    """wb = bf16 weights, wf = fp32 params (biases). 3 launches: the fused torso (conv1-3, activations in LDS),
+    FC1(+bias+ReLU), head(+dueling[+ε-greedy]). frame_off given: x_u8 is a replay store of single planes and conv1 uses the
+    pack's (c, kh, kw) weights; dense HWC stacks (actors, frame_off None) need ``w1`` = the HWC-ordered copy
+    (models.packing.conv1_hwc)."""
     assert (frame_off is None) == (w1 is not None), "dense HWC input <-> HWC-ordered conv1 weights"
-    H.conv_fwd(1, x_u8, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
-    H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, n)
-    H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, n)
+    if H.TORSO_FUSED:
+        H.torso_fwd(x_u8, torso_net(buf.__dict__.setdefault("_torso", {}), frame_off, n, wb, wf, None, None, buf.act3, w1=w1))
+    else:
+        H.conv_fwd(1, x_u8, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), buf.act1, n, frame_off)
+        H.conv_fwd(2, buf.act1, wb.view("conv2.w"), wf.view("conv2.b"), buf.act2, n)
+        H.conv_fwd(3, buf.act2, wb.view("conv3.w"), wf.view("conv3.b"), buf.act3, n)
     # FC1: 64x64 tiles, LDS-DMA mainloop with 4 stages (variant 10): 17.6 us vs 20.9 us for the register ring at n = 1024
     H.gemm(H.NT, buf.act3, wb.view("fc1.w"), buf.h, n, 1024, 3136, bias=wf.view("fc1.b"), flags=H.EPI_RELU, big=H.FC1_FWD_VARIANT)
     H.head_fwd(buf.h, wb.view("adv2.w"), wf.view("adv2.b"), wb.view("val2.w"), wf.view("val2.b"), buf.q, action_out,
@@ -63,17 +80,26 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 
 def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
-                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers, prep=None) -> None:
-    """Forward of TWO networks (online on n1 frames, target on n2 frames), 5 launches in total: each layer of both networks
-    is one launch, so the learner's step needs no second stream (no fork / join) for the target network. (Sharing the s'
+                       off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers, prep=None,
+                       save1: Optional[int] = None) -> None:
+    """Forward of TWO networks (online on n1 frames, target on n2 frames), 3 launches in total: the torso, FC1 and the head
+    of both networks are one launch each, so the learner's step needs no second stream (no fork / join) for the target
+    network. ``save1``: how many of network 1's leading frames a backward pass will read (default: all). (Sharing the s'
     tiles of conv1 between the two networks inside that launch was measured and dropped: 0.2465 vs 0.2400 ms per step, the
     heavier pair blocks set the launch's registers and its tail.)"""
-    H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
-                    wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
-    for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
-        H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
-                        getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst),
-                        prep=prep if l == 2 else None)
+    if H.TORSO_FUSED:
+        # ONE launch for conv1-3 of both networks; act1 / act2 reach HBM only for network 1's frames [0, save1): the ones
+        # a backward pass reads (Ape-X: the B online-s frames of 3 B forwards)
+        cache = b1.__dict__.setdefault("_torso", {})
+        H.torso_fwd(x_u8, torso_net(cache, off1, n1, wb1, wf1, b1.act1, b1.act2, b1.act3, save=(0, n1 if save1 is None else save1)),
+                    torso_net(cache, off2, n2, wb2, wf2, None, None, b2.act3), prep=prep)
+    else:
+        H.conv_fwd_dual(1, x_u8, n1, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1, None, n2, wb2.view("conv1.w"),
+                        wf2.view("conv1.b"), b2.act1, frame_off1=off1, frame_off2=off2)
+        for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
+            H.conv_fwd_dual(l, getattr(b1, src), n1, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst),
+                            getattr(b2, src), n2, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst),
+                            prep=prep if l == 2 else None)
     H.gemm_nt_dual(b1.act3, wb1.view("fc1.w"), wf1.view("fc1.b"), b1.h, b2.act3, wb2.view("fc1.w"), wf2.view("fc1.b"), b2.h,
                    1024, 3136, flags=H.EPI_RELU)
     H.head_fwd_dual(b1.h, wb1.view("adv2.w"), wf1.view("adv2.b"), wb1.view("val2.w"), wf1.view("val2.b"), b1.q,
@@ -164,7 +190,7 @@ class ApexEngine(ShardedIS):
             r.sample(self.st, begin=True, is_n_scale=1.0, n_is=self.n_is)
         prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None
         torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
-                           prep=prep)
+                           prep=prep, save1=B)
         G, Pb, on = self.G, self.Pb, self.on
         h, a3 = on.h[:B], on.act3[:B]
         # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)

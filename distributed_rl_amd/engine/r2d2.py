@@ -32,6 +32,7 @@ from ..models.packing import ParamPack, r2d2_layout
 from ..ops import hip as H
 from .guard import StepGuard
 from .shard import ShardedIS
+from .apex import torso_net
 from .streams import ForkJoin, capture_graph
 from ..replay.device_seq import DeviceSequenceReplay
 
@@ -59,9 +60,17 @@ def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
     return persistent and H.use_lib_gemm(n, 4 * Hd, 3136)
 
 
+def _save_range(save_from: Optional[int], B: int, r0: int, n: int) -> Tuple[int, int]:
+    """Frames [lo, n) of a chunk that starts at row r0 whose act1 / act2 a backward pass reads: time steps >= save_from."""
+    if save_from is None:
+        return (0, 0)
+    lo = min(max(save_from * B - r0, 0), n)
+    return (lo, n) if lo < n else (0, 0)
+
+
 def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: int, B: int, Hd: int, wb: ParamPack,
                       wf: ParamPack, buf: SeqNetBuffers, bsum: torch.Tensor, steps: Optional[Tuple[int, int]] = None,
-                      persistent: bool = False, prep=None, w1=None) -> None:
+                      persistent: bool = False, prep=None, w1=None, save_from: Optional[int] = 0) -> None:
     """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
     all T) + ONE input-projection GEMM for those steps (throughput-bound). ``persistent``: the recurrence that follows is
     the persistent kernel (it may take over the bias add, see defer_xg_bias)."""
@@ -73,9 +82,14 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     # frame_off given: the frames are plane windows of the replay store, conv1 weights in the pack's (c, kh, kw) order; dense
     # HWC stacks (the actors' sequence-priority pass) need w1 = the HWC-ordered copy (models.packing.conv1_hwc)
     assert (frame_off is None) == (w1 is not None), "dense HWC input <-> HWC-ordered conv1 weights"
-    H.conv_fwd(1, x, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
-    H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n, prep=prep if t0 == 0 else None)
-    H.conv_fwd(3, a2, wb.view("conv3.w"), wf.view("conv3.b"), a3, n)
+    if H.TORSO_FUSED:
+        # ONE launch; act1 / act2 reach HBM only from time step ``save_from`` on (None: never): what a backward pass reads
+        H.torso_fwd(x, torso_net(buf.__dict__.setdefault("_torso", {}), fo, n, wb, wf, a1, a2, a3,
+                                 save=_save_range(save_from, B, r0, n), w1=w1), prep=prep if t0 == 0 else None)
+    else:
+        H.conv_fwd(1, x, w1 if w1 is not None else wb.view("conv1.w"), wf.view("conv1.b"), a1, n, fo)
+        H.conv_fwd(2, a1, wb.view("conv2.w"), wf.view("conv2.b"), a2, n, prep=prep if t0 == 0 else None)
+        H.conv_fwd(3, a2, wb.view("conv3.w"), wf.view("conv3.b"), a3, n)
     if t0 == 0:
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
     xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
@@ -90,20 +104,27 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
 
 
 def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
-                           steps: Tuple[int, int], persistent: bool, prep=None, free_cus: int = 256) -> None:
-    """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target), each conv layer as one
-    launch (the second network's read of a frame finds it in the Infinity Cache). net = (wb, wf, buf, bsum)."""
+                           steps: Tuple[int, int], persistent: bool, prep=None, free_cus: int = 256,
+                           save_from: Optional[int] = 0) -> None:
+    """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target): the torso of both as one
+    launch (the second network's read of a frame finds it in the Infinity Cache); only network 1 keeps act1 / act2, from
+    time step ``save_from`` on. net = (wb, wf, buf, bsum)."""
     t0, t1 = steps
     r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
     fo = frame_off[r0:r1]
     (wb1, wf1, b1, bs1), (wb2, wf2, b2, bs2) = net1, net2
-    if os.environ.get("DRL_CONV1_PAIR", "1") != "0":   # every frame read and converted once, two weight sets per tile
+    if H.TORSO_FUSED:
+        cache = b1.__dict__.setdefault("_torso", {})
+        H.torso_fwd(frames, torso_net(cache, fo, n, wb1, wf1, b1.act1[r0:r1], b1.act2[r0:r1], b1.act3[r0:r1],
+                                      save=_save_range(save_from, B, r0, n)),
+                    torso_net(cache, fo, n, wb2, wf2, None, None, b2.act3[r0:r1]), prep=prep if t0 == 0 else None)
+    elif os.environ.get("DRL_CONV1_PAIR", "1") != "0":   # every frame read and converted once, two weight sets per tile
         H.conv1_fwd_pair(frames, fo, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], wb2.view("conv1.w"),
                          wf2.view("conv1.b"), b2.act1[r0:r1])
     else:
         H.conv_fwd_dual(1, frames, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], None, n, wb2.view("conv1.w"),
                         wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
-    for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")):
+    for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")) if not H.TORSO_FUSED else ():
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
                         getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1],
                         prep=prep if (l == 2 and t0 == 0) else None)
@@ -165,7 +186,7 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
     """Q values of one DuelingLSTMDQN over T x B frames (time-major), starting from the state in buf.hs[0] / buf.cs[0].
     Shared by the learner (frames addressed in the replay store through ``frame_off``) and the actor-side
     sequence-priority pass (dense frames, ``frame_off`` None)."""
-    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum, persistent=persistent, w1=w1)
+    seq_torso_forward(frames, frame_off, T, B, Hd, wb, wf, buf, bsum, persistent=persistent, w1=w1, save_from=None)
     seq_recurrent_forward(T, B, Hd, wb, wf, buf, persistent, bsum=bsum)
 
 
@@ -334,15 +355,15 @@ class R2D2Engine(ShardedIS):
                     with H.halo_busy(64 if (st_[0] > 0 and self.busy_aware) else 0):
                         seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
                                                (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep,
-                                               free_cus=256 - 64 * self.fwd_groups_busy(st_))
+                                               free_cus=256 - 64 * self.fwd_groups_busy(st_), save_from=burn)
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
-                                      persistent=pl, prep=prep)
+                                      persistent=pl, prep=prep, save_from=burn)
                     if not dual:
                         with fj.fork(0):
                             seq_recurrence(T, B, Hd, self.Pb, self.on, pl, steps=st_, bsum=self.bsum_on)
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Tb, self.Tg, self.tg, self.bsum_tg, steps=st_,
-                                      persistent=pl)
+                                      persistent=pl, save_from=None)
                 if dual:
                     # both recurrences of the chunk in ONE persistent launch (64 workgroups): 685 us for 120 steps of two
                     # nets against 655 us for one, so the second network rides along almost for free
@@ -380,7 +401,7 @@ class R2D2Engine(ShardedIS):
                     seq_heads(T, B, Hd, self.Tb, self.Tg, self.tg)
         else:
             seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on,
-                              persistent=self.persistent_lstm, prep=prep)
+                              persistent=self.persistent_lstm, prep=prep, save_from=burn)
             with fj.fork(0):                                        # target net: queued behind the online torso
                 self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
             seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm, bsum=self.bsum_on)

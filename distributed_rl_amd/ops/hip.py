@@ -368,6 +368,10 @@ CONV_HALO_VARIANT = {2: int(os.environ.get("DRL_CONV2_HALO_VARIANT", "-1")), 3: 
 import contextlib
 
 
+# conv1 -> conv2 -> conv3 of a forward pass as ONE launch (conv_torso.hip). DRL_TORSO_FUSED=0: one launch per layer (A/B).
+TORSO_FUSED = os.environ.get("DRL_TORSO_FUSED", "1") != "0"
+
+
 @contextlib.contextmanager
 def halo_busy(cus: int, lds_bytes: int = 66 * 1024):
     """The LDS-halo launches issued inside run next to a PERSISTENT kernel of another stream that holds ``cus`` CUs with
@@ -377,11 +381,13 @@ def halo_busy(cus: int, lds_bytes: int = 66 * 1024):
     lib = native.hip()
     if cus > 0:
         _ck(lib.drl_halo_set_busy(cus, lds_bytes), "halo_set_busy")
+        _ck(lib.drl_torso_set_busy(cus), "torso_set_busy")      # the fused torso fills a CU's registers: it leaves those CUs out
     try:
         yield 256 - cus
     finally:
         if cus > 0:
             lib.drl_halo_set_busy(0, 0)
+            lib.drl_torso_set_busy(0)
 
 
 def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w2=None, b2=None, out2=None,
