@@ -28,6 +28,7 @@
 // 102 slots) = 79 392 B: the layouts of conv_halo.hip (scripts/debug/halo_lds_layout.py).
 #include "common.h"
 #include "conv_frag.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 torso_bf16x8;
 __device__ __forceinline__ f32x4 torso_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -44,7 +45,8 @@ struct TorsoNet {
 
 constexpr int T_P1 = 5, T_RP1 = 101, T_IMG1 = 2020 * 16;     // conv2's input image: slots of 16 bytes
 constexpr int T_P2 = 10, T_RP2 = 102, T_IMG2 = 922 * 16;     // conv3's input image
-constexpr int T_LDS = 2 * T_IMG1 + T_IMG2;
+constexpr int T_RAW = 2 * T_IMG1 + T_IMG2, T_RAWSZ = 28672;   // two raw-frame buffers (28 224 bytes used) behind the images
+constexpr int T_LDS = T_RAW + 2 * T_RAWSZ;
 
 // every LDS access of this wave has completed, then the workgroup barrier; vector-memory operations stay in flight
 __device__ __forceinline__ void torso_barrier() {
@@ -53,7 +55,7 @@ __device__ __forceinline__ void torso_barrier() {
 }
 
 template <bool OFF>
-__global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict__ x, TorsoNet n1, TorsoNet n2, HaloPrep prep) {
+__global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict__ x, TorsoNet n1, TorsoNet n2, HaloPrep prep, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // image1[0], image1[1], image2
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     if ((int)blockIdx.x >= n1.nblk + n2.nblk) {                         // the weight pre-pass workgroups (conv_frag.h)
@@ -108,63 +110,150 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
         const int gofs0 = (wave * 16 + r) * 64 + g * 16, gofs6 = (24 * 16 + r) * 64 + g * 16;   // slot j: pixel m0 + 64 j; slot 6: tile 24
         auto koff = [](int s) -> int { return OFF ? (s >> 1) * 7056 + (s & 1) * 336 : s * 336; };
         auto frame_of = [&](int i) -> int { return blk + min(i, nf - 1) * nblk; };          // wave-uniform
-        // the frame's base is a SCALAR load (constant address space: the list is read-only for the launch); as a vector
-        // load its wait would drain the whole prefetch (vmcnt counts in order)
+        // the frame's base is a SCALAR load (constant address space: the list is read-only for the launch)
         typedef const long long __attribute__((address_space(4)))* const_ll_ptr;
         auto fbase = [&](int f) -> long long {
             if constexpr (OFF) return ((const_ll_ptr)frame_off)[f];
             else return (long long)f * 28224;
         };
-        uint2 buf[7][8];
-        auto issue = [&](uint2 (&b)[8], long long fb, int j) __attribute__((always_inline)) {
+        // The raw frame (4 planes / one HWC stack = 28 224 contiguous bytes) goes global -> LDS by LDS-DMA, 16 bytes per
+        // lane, 7 instructions per P wave, one whole round before conv1 reads it: HBM is read once and coalesced (the
+        // direct global -> VGPR form of conv_direct.hip reads every byte 4 times through L1 and needs 16 VGPRs per tile in
+        // flight), and no register waits for memory. Chunks past the frame's end re-read its last chunk.
+        typedef const __attribute__((address_space(1))) void* t_gptr;
+        typedef __attribute__((address_space(3))) void* t_lptr;
+        auto dma = [&](long long fb, unsigned raw) __attribute__((always_inline)) {
+            const uint8_t* __restrict__ fp = x + fb;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const uint2*>(x + fb + pofs[j] + koff(s));
-        };
-        // one slot: 16 MFMAs, bias + ReLU, 16 bytes into the image (and into HBM where a backward will read them); then the
-        // slot's registers are re-loaded with the same slot of the next frame
-        auto slot = [&](int j, unsigned img, int frame, long long fb_next) __attribute__((always_inline)) {
-            f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const uint4 xf = u8x8_to_f16_biased(buf[j][s]);
-                acc[0] = mfma16h(wf[0][s], xf, acc[0]);
-                acc[1] = mfma16h(wf[1][s], xf, acc[1]);
+            for (int i = 0; i < 7; ++i) {
+                const int chunk0 = (i * 4 + wave) * 64;                                  // wave-uniform
+                const void* g_ = fp + (unsigned)min(chunk0 + lane, 1763) * 16u;
+                __builtin_amdgcn_global_load_lds((t_gptr)g_, (t_lptr)(smem + raw + chunk0 * 16), 16, 0, 0);
             }
-            issue(buf[j], fb_next, j);
+        };
+        // LDS accesses of the P waves are INLINE ASM on purpose: hipcc (ROCm 7.2) orders every ds instruction it can see
+        // behind the pending LDS-DMAs with an s_waitcnt vmcnt(0) - the DMA of the NEXT frame would be drained right after
+        // its issue. The compiler does not count these reads: every use is behind an explicit s_waitcnt lgkmcnt(0).
+        typedef uint32_t t_u32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t t_u32x4 __attribute__((ext_vector_type(4)));
+        // fragments of one slot (8 k-steps x 8 bytes per lane). Plane store: k-step s = plane s / 2, patch rows 4 (s % 2) ..
+        // (4-byte aligned: two dwords per read); dense stacks: patch row s (8-byte aligned)
+        auto rd_slot = [&](t_u32x2 (&f)[8], unsigned raw, int j) __attribute__((always_inline)) {
+            if constexpr (OFF) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned a_ = raw + (unsigned)pofs[j] + (unsigned)c * 7056u;
+                    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(f[2 * c]) : "v"(a_));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:84 offset1:85" : "=v"(f[2 * c + 1]) : "v"(a_));
+                }
+            } else {
+                const unsigned a_ = raw + (unsigned)pofs[j];
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f[s_]) : "v"(a_), "n"(s_ * 336));
+            }
+        };
+        // one group = N slots (j0 ..) at once: 2 N independent accumulator chains (an MFMA result is ready ~36 cycles after
+        // issue: one slot alone, 2 chains of 8 dependent MFMAs, runs at half the pipe's rate). Then bias + ReLU, 16 bytes into
+        // the image (SAVE: and into HBM, where a backward will read them; a template parameter, not a branch per slot).
+        auto compute = [&](auto n_tag, auto save_tag, t_u32x2 (&fr)[2][8], int j0, unsigned img, int frame) __attribute__((always_inline)) {
+            constexpr int N = decltype(n_tag)::value;
+            constexpr bool SAVE = decltype(save_tag)::value;
+            f32x4 acc[N][2];
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[q][t] = f32x4{acc0[t][0], acc0[t][1], acc0[t][2], acc0[t][3]};
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+                    const uint4 xf = u8x8_to_f16_biased(make_uint2(fr[q][s_][0], fr[q][s_][1]));
+                    acc[q][0] = mfma16h(wf[0][s_], xf, acc[q][0]);
+                    acc[q][1] = mfma16h(wf[1][s_], xf, acc[q][1]);
+                }
+            }
             constexpr float SC = 1.0f / 255.0f;          // pixel normalisation x/255 folded into the epilogue
-            uint32_t o[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                o[2 * t] = pack_bf2(fmaxf(acc[t][0] * SC + b4[t].x, 0.f), fmaxf(acc[t][1] * SC + b4[t].y, 0.f));
-                o[2 * t + 1] = pack_bf2(fmaxf(acc[t][2] * SC + b4[t].z, 0.f), fmaxf(acc[t][3] * SC + b4[t].w, 0.f));
+            for (int q = 0; q < N; ++q) {
+                const int j = j0 + q;
+                t_u32x4 ov;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ov[2 * t] = pack_bf2(fmaxf(acc[q][t][0] * SC + b4[t].x, 0.f), fmaxf(acc[q][t][1] * SC + b4[t].y, 0.f));
+                    ov[2 * t + 1] = pack_bf2(fmaxf(acc[q][t][2] * SC + b4[t].z, 0.f), fmaxf(acc[q][t][3] * SC + b4[t].w, 0.f));
+                }
+                const unsigned la = img + (unsigned)lofs[j];
+                asm volatile("ds_write_b128 %0, %1" : : "v"(la), "v"(ov) : "memory");
+                if constexpr (SAVE)
+                    *reinterpret_cast<t_u32x4*>(reinterpret_cast<uint8_t*>(act1) + (long long)frame * 25600 +
+                                                (unsigned)(j < 6 ? gofs0 + 4096 * j : gofs6)) = ov;
             }
-            const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<uint4*>(smem + img + lofs[j]) = ov;
-            if (frame >= save_lo && frame < save_hi)     // wave-uniform
-                *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(act1) + (long long)frame * 25600 + (j < 6 ? gofs0 + 4096 * j : gofs6)) = ov;
         };
-        {
-            const long long fb0 = fbase(frame_of(0));
+        using one_t = std::integral_constant<int, 1>;
+        using two_t = std::integral_constant<int, 2>;
+        t_u32x2 fa[2][8], fb_[2][8];                     // fragment registers of two groups: one computing, one being read
+        // the reads of group f have landed: the wait takes the group's registers as operands, so no use of them can be
+        // scheduled in front of it (the compiler does not know what the ds_read asm statements leave in flight)
+        auto land = [](t_u32x2 (&f)[2][8]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[0][3]), "+v"(f[0][4]), "+v"(f[0][5]), "+v"(f[0][6]), "+v"(f[0][7]),
+                           "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]), "+v"(f[1][3]), "+v"(f[1][4]), "+v"(f[1][5]), "+v"(f[1][6]), "+v"(f[1][7])
+                         :: "memory");
+        };
+        // groups of a frame: (0, 1) (2, 3) | barrier | (4, 5) (6). The reads of a group are issued before the group in front
+        // of it is computed.
+        auto seg_a = [&](auto save_tag, unsigned raw, unsigned img, int f) __attribute__((always_inline)) {
+            rd_slot(fa[0], raw, 0); rd_slot(fa[1], raw, 1);
+            land(fa);
+            rd_slot(fb_[0], raw, 2); rd_slot(fb_[1], raw, 3);
+            compute(two_t{}, save_tag, fa, 0, img, f);
+            land(fb_);
+            rd_slot(fa[0], raw, 4); rd_slot(fa[1], raw, 5);
+            compute(two_t{}, save_tag, fb_, 2, img, f);
+        };
+        auto seg_b = [&](auto save_tag, unsigned raw, unsigned img, int f) __attribute__((always_inline)) {
+            land(fa);
+            rd_slot(fb_[0], raw, 6);
+            compute(two_t{}, save_tag, fa, 4, img, f);
+            land(fb_);
+            compute(one_t{}, save_tag, fb_, 6, img, f);
+        };
+        // land weights and biases BEFORE the first DMA is issued (their first use would otherwise wait behind the DMAs)
 #pragma unroll
-            for (int j = 0; j < 7; ++j) issue(buf[j], fb0, j);
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) asm volatile("" : "+v"(wf[t][s_].x), "+v"(wf[t][s_].y), "+v"(wf[t][s_].z), "+v"(wf[t][s_].w));
+            asm volatile("" : "+v"(b4[t].x), "+v"(b4[t].y), "+v"(b4[t].z), "+v"(b4[t].w));
+            asm volatile("" : "+v"(acc0[t][0]), "+v"(acc0[t][1]), "+v"(acc0[t][2]), "+v"(acc0[t][3]));
         }
+        dma(fbase(frame_of(0)), T_RAW);
+        dma(fbase(frame_of(1)), T_RAW + T_RAWSZ);
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        torso_barrier();                                 // frame 0 is in raw[0]
         {                                                // frame 0 -> image1[0], before the first round
             const int f = frame_of(0);
-            const long long fbn = fbase(frame_of(1));
-#pragma unroll
-            for (int j = 0; j < 7; ++j) slot(j, 0u, f, fbn);
+            if (f >= save_lo && f < save_hi) { seg_a(std::true_type{}, T_RAW, 0u, f); seg_b(std::true_type{}, T_RAW, 0u, f); }
+            else { seg_a(std::false_type{}, T_RAW, 0u, f); seg_b(std::false_type{}, T_RAW, 0u, f); }
         }
-        torso_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        torso_barrier();                                 // frame 1 is in raw[1], frame 0 in image1[0]
         for (int i = 0; i < nf; ++i) {
-            // in the last round this is the last frame once more (same values to the same places): no branch in the loop
+            // in the last round this is the last frame once more (same values to the same places): no special case
             const int f = frame_of(i + 1);
-            const long long fbn = fbase(frame_of(i + 2));
-            const unsigned img = ((i + 1) & 1) * T_IMG1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) slot(j, img, f, fbn);
+            const unsigned img = ((i + 1) & 1) * T_IMG1, raw = T_RAW + ((i + 1) & 1) * T_RAWSZ;
+            const bool save = f >= save_lo && f < save_hi;      // wave-uniform
+            dma(fbase(frame_of(i + 2)), T_RAW + (i & 1) * T_RAWSZ);   // raw[i & 1] held frame i: read in round i - 1
+            if (!(dbg & 1)) {
+                if (save) seg_a(std::true_type{}, raw, img, f);
+                else seg_a(std::false_type{}, raw, img, f);
+            }
             torso_barrier();
-#pragma unroll
-            for (int j = 4; j < 7; ++j) slot(j, img, f, fbn);
+            if (!(dbg & 1)) {
+                if (save) seg_b(std::true_type{}, raw, img, f);
+                else seg_b(std::false_type{}, raw, img, f);
+            }
+            if (save && !(dbg & 1)) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             torso_barrier();
         }
     } else {
@@ -206,10 +295,12 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
         for (int s = 0; s < 18; ++s) asm volatile("" : "+v"(wf3[s]));
         asm volatile("" : "+v"(bb2.x), "+v"(bb2.y), "+v"(bb2.z), "+v"(bb2.w), "+v"(bb3.x), "+v"(bb3.y), "+v"(bb3.z), "+v"(bb3.w));
         __builtin_amdgcn_s_setprio(1);              // the second-dispatched half loses every arbitration otherwise
+        torso_barrier();                            // (P: frame 0 is in raw[0])
         torso_barrier();                            // frame 0 is in image1[0]
         for (int i = 0; i < nf; ++i) {
             const int frame = blk + i * nblk;
             const unsigned cur = (i & 1) * T_IMG1;
+            if (!(dbg & 2))
             {   // ---- conv2: 6 tiles x 16 k-steps (k-step = one tap of the 4x4 kernel x 32 channels) ----
                 f32x4 acc[6];
 #pragma unroll
@@ -224,24 +315,31 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
                 __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    if (s + 1 < 16) {
-                        rd(xf[(s + 1) & 1], s + 1);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // 6 ds reads of k-step s + 1 ...
-                    }
+                    if (s + 1 < 16) rd(xf[(s + 1) & 1], s + 1);
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) acc[u] = torso_mfma(wf2[s], xf[s & 1][u], acc[u]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);              // ... then the 6 MFMAs of k-step s
+                    for (int u = 0; u < 6; ++u) {
+                        acc[u] = torso_mfma(wf2[s], xf[s & 1][u], acc[u]);
+                        // one ds read of k-step s + 1 in the issue gap behind every MFMA of k-step s (a block of 6 reads
+                        // between the MFMA blocks leaves the pipe idle while they issue)
+                        if (s + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
                 }
-                const bool save = frame >= save_lo && frame < save_hi;              // wave-uniform
+                uint2 o[6];
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
-                    const uint2 o = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb2.x, 0.f), fmaxf(acc[u][1] + bb2.y, 0.f)),
-                                               pack_bf2(fmaxf(acc[u][2] + bb2.z, 0.f), fmaxf(acc[u][3] + bb2.w, 0.f)));
-                    *reinterpret_cast<uint2*>(smem + wo2[u]) = o;
-                    if (save) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(act2) + (long long)frame * 10368 + go2[u]) = o;
+                    o[u] = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb2.x, 0.f), fmaxf(acc[u][1] + bb2.y, 0.f)),
+                                      pack_bf2(fmaxf(acc[u][2] + bb2.z, 0.f), fmaxf(acc[u][3] + bb2.w, 0.f)));
+                    *reinterpret_cast<uint2*>(smem + wo2[u]) = o[u];
+                }
+                if (frame >= save_lo && frame < save_hi) {                          // wave-uniform, ONE branch per frame
+                    uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(act2) + (long long)frame * 10368;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) *reinterpret_cast<uint2*>(dst + go2[u]) = o[u];
                 }
             }
             torso_barrier();
+            if (!(dbg & 4))
             {   // ---- conv3: 4 tiles x 18 k-steps (k-step = half the 64 channels of one tap of the 3x3 kernel) ----
                 f32x4 acc[4];
 #pragma unroll
@@ -257,19 +355,20 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                 for (int s = 0; s < 18; ++s) {
-                    if (s + 1 < 18) {
-                        rd(xf[(s + 1) & 1], s + 1);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    }
+                    if (s + 1 < 18) rd(xf[(s + 1) & 1], s + 1);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[u] = torso_mfma(wf3[s], xf[s & 1][u], acc[u]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        acc[u] = torso_mfma(wf3[s], xf[s & 1][u], acc[u]);
+                        if (s + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
                 }
+                uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(act3) + (long long)frame * 6272;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint2 o = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb3.x, 0.f), fmaxf(acc[u][1] + bb3.y, 0.f)),
                                                pack_bf2(fmaxf(acc[u][2] + bb3.z, 0.f), fmaxf(acc[u][3] + bb3.w, 0.f)));
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(act3) + (long long)frame * 6272 + go3[u]) = o;
+                    *reinterpret_cast<uint2*>(dst + go3[u]) = o;
                 }
             }
             torso_barrier();
@@ -279,7 +378,8 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
 
 // CUs that a concurrently running persistent kernel of another stream occupies (conv_halo.hip: drl_halo_set_busy). A torso
 // workgroup fills a CU's registers: it cannot share one, so the grid leaves those CUs out.
-static int g_torso_busy_cus = 0;
+static int g_torso_busy_cus = 0, g_torso_dbg = 0;
+DRL_API int drl_torso_set_debug(int d) { g_torso_dbg = d; return 0; }
 DRL_API int drl_torso_set_busy(int cus) {
     if (cus < 0 || cus > 192) return -1;
     g_torso_busy_cus = cus;
@@ -335,11 +435,11 @@ DRL_API int drl_torso_fwd(const void* x,
     if (off1) {
         static bool once = ((void)hipFuncSetAttribute((const void*)k_torso_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS), true);
         (void)once;
-        k_torso_fwd<true><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep);
+        k_torso_fwd<true><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep, g_torso_dbg);
     } else {
         static bool once = ((void)hipFuncSetAttribute((const void*)k_torso_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS), true);
         (void)once;
-        k_torso_fwd<false><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep);
+        k_torso_fwd<false><<<grid, 512, T_LDS, s>>>((const uint8_t*)x, n1, n2, prep, g_torso_dbg);
     }
     return (int)hipGetLastError();
 }

@@ -47,6 +47,7 @@ SIGS = {
     # conv_torso.hip
     "drl_torso_fwd": [P, P, I, P, P, P, I, I, P, I, P, P, P, I, I, P, P, P, P, P],
     "drl_torso_set_busy": [I],
+    "drl_torso_set_debug": [I],
     # conv_wgrad_halo.hip
     "drl_conv_wgrad_halo": [I, P, P, P, P, P, I, I, P],
     "drl_conv1_wgrad_halo": [P, P, P, P, P, P, I, I, P],

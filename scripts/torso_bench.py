@@ -39,12 +39,19 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default="", help="substring of the case name")
+    ap.add_argument("--eager", action="store_true", help="a few eager launches of the fused kernel only (for rocprofv3 --pmc)")
+    ap.add_argument("--dbg", type=int, default=0, help="skip roles of the fused kernel (1: conv1, 2: conv2, 4: conv3): timing only")
     args = ap.parse_args()
+    from distributed_rl_amd import native
+    native.hip().drl_torso_set_debug(args.dbg)
     planes = 60000
     store = torch.randint(0, 256, (planes, 7056), dtype=torch.uint8, device=DEV)
     for name, f1, f2, save in (("apex B=512 (online 1024 + target 512)", 1024, 512, (0, 512)),
                                ("r2d2 chunk (online 4608 + target 4608)", 4608, 4608, (2560, 4608)),
                                ("actor 64 envs", 64, 0, (0, 0)), ("one net 1536", 1536, 0, (0, 0))):
+        if args.only and args.only not in name:
+            continue
         off = (torch.randint(0, planes - 4, (f1 + f2,), device=DEV) * 7056)
         n1 = net(1, f1, off[:f1].contiguous(), save)
         n2 = net(2, f2, off[f1:].contiguous(), (0, 0)) if f2 else None
@@ -64,6 +71,11 @@ def main():
         def fused():
             H.torso_fwd(store, n1["t"], n2["t"] if n2 else None)
 
+        if args.eager:
+            for _ in range(5):
+                fused()
+            torch.cuda.synchronize()
+            continue
         t3, tf = timeit(three, args.reps), timeit(fused, args.reps)
         flops = (f1 + f2) * 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576)
         print(json.dumps({"case": name, "three_launch_us": round(t3, 2), "fused_us": round(tf, 2),
