@@ -124,12 +124,29 @@ struct alignas(kCacheLine) ParamHeader {
     std::atomic<uint64_t> writing;                       // version currently being written (seqlock guard)
 };
 
+// Device mirror of the parameter register (second kilobyte of the header page): the learner keeps the two newest
+// versions in a double buffer in ITS GPU's memory and exports it by IPC handle; actors on the same GPU copy device to
+// device instead of D2H -> shm -> H2D. slot_ver[v & 1] == v says that slot holds version v completely (0: being written).
+struct alignas(kCacheLine) MirrorRecord {
+    std::atomic<uint64_t> valid;                         // 0 = no mirror; else the exporting process' pid
+    uint64_t slot_bytes;
+    uint8_t handle[64];                                  // hipIpcMemHandle_t of the double buffer
+    char bus_id[64];                                     // PCI bus id of the GPU that holds it
+    alignas(kCacheLine) std::atomic<uint64_t> latest;
+    std::atomic<uint64_t> slot_ver[2];
+};
+constexpr size_t kMirrorOffset = 1024;
+static_assert(sizeof(ParamHeader) <= kMirrorOffset && kMirrorOffset + sizeof(MirrorRecord) <= 4096, "header page layout");
+
 struct Param {
     Mapping map;
     ParamHeader* hdr;
     uint8_t* buf[2];
     std::string name;
 };
+static MirrorRecord* mirror_of(void* h) {
+    return reinterpret_cast<MirrorRecord*>(static_cast<uint8_t*>(static_cast<Param*>(h)->map.base) + kMirrorOffset);
+}
 
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxBeats = 1024;
@@ -341,6 +358,8 @@ void drl_param_close(void* h, int unlink_it) {
 
 uint64_t drl_param_capacity(void* h) { return static_cast<Param*>(h)->hdr->capacity; }
 uint64_t drl_param_version(void* h) { return static_cast<Param*>(h)->hdr->version.load(std::memory_order_acquire); }
+// payload size of version v (valid while v is one of the two newest versions)
+uint64_t drl_param_nbytes(void* h, uint64_t v) { return static_cast<Param*>(h)->hdr->nbytes[v & 1].load(std::memory_order_acquire); }
 
 // Single writer. Returns the new version, or 0 if too large.
 uint64_t drl_param_publish(void* h, const void* data, uint64_t nbytes) {
@@ -360,6 +379,9 @@ void drl_param_reset(void* h) {
     Param* p = static_cast<Param*>(h);
     p->hdr->writing.store(0, std::memory_order_relaxed);
     p->hdr->version.store(0, std::memory_order_release);
+    MirrorRecord* m = mirror_of(h);
+    m->latest.store(0, std::memory_order_relaxed);
+    m->slot_ver[0].store(0, std::memory_order_relaxed); m->slot_ver[1].store(0, std::memory_order_release);
 }
 
 // Copy the latest version into `out` if it is newer than `have_version`.
@@ -377,6 +399,45 @@ uint64_t drl_param_read(void* h, void* out, uint64_t out_capacity, uint64_t have
         if (w < v + 2) { *nbytes_out = nb; return v; }   // the writer has not started overwriting our buffer
     }
     return 0;
+}
+
+// ---- device mirror of the register (see MirrorRecord) -------------------------------------------------
+void drl_param_mirror_set(void* h, const void* handle64, const char* bus_id, uint64_t slot_bytes, uint64_t pid) {
+    MirrorRecord* m = mirror_of(h);
+    m->valid.store(0, std::memory_order_release);
+    m->latest.store(0, std::memory_order_relaxed);
+    m->slot_ver[0].store(0, std::memory_order_relaxed); m->slot_ver[1].store(0, std::memory_order_relaxed);
+    memcpy(m->handle, handle64, 64);
+    memset(m->bus_id, 0, sizeof(m->bus_id));
+    strncpy(m->bus_id, bus_id, sizeof(m->bus_id) - 1);
+    m->slot_bytes = slot_bytes;
+    m->valid.store(pid ? pid : 1, std::memory_order_release);
+}
+void drl_param_mirror_clear(void* h) { mirror_of(h)->valid.store(0, std::memory_order_release); }
+// returns the exporter's pid (0: none)
+uint64_t drl_param_mirror_get(void* h, void* handle64_out, char* bus_id_out64, uint64_t* slot_bytes_out) {
+    MirrorRecord* m = mirror_of(h);
+    uint64_t pid = m->valid.load(std::memory_order_acquire);
+    if (!pid) return 0;
+    memcpy(handle64_out, m->handle, 64);
+    memcpy(bus_id_out64, m->bus_id, 64);
+    *slot_bytes_out = m->slot_bytes;
+    return m->valid.load(std::memory_order_acquire) == pid ? pid : 0;
+}
+// writer: begin(v) before the device copy into slot v & 1 is enqueued, end(v) after it has COMPLETED
+void drl_param_mirror_begin(void* h, uint64_t v) {
+    mirror_of(h)->slot_ver[v & 1].store(0, std::memory_order_seq_cst);
+}
+void drl_param_mirror_end(void* h, uint64_t v) {
+    MirrorRecord* m = mirror_of(h);
+    m->slot_ver[v & 1].store(v, std::memory_order_release);
+    m->latest.store(v, std::memory_order_release);
+}
+uint64_t drl_param_mirror_latest(void* h) { return mirror_of(h)->latest.load(std::memory_order_acquire); }
+// reader, after its copy out of slot v & 1 has completed: 1 if the slot held version v the whole time
+int drl_param_mirror_check(void* h, uint64_t v) {
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    return mirror_of(h)->slot_ver[v & 1].load(std::memory_order_acquire) == v ? 1 : 0;
 }
 
 // ---- HeartbeatTable ---------------------------------------------------------------------------------

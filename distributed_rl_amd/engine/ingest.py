@@ -56,6 +56,10 @@ class AsyncIngest:
         # pinned staging buffers + one device priority buffer each (the commit kernel reads priorities from HBM)
         self._bufs = [torch.empty(self.slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self._prio = [torch.zeros(max_items, device=self.device) for _ in range(depth)]
+        # device copy of a block's tables (everything behind its planes): the replay scatters them with one launch
+        self._tail = [torch.zeros(1 << 16, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self._prio_view = [None] * depth
+        self.fast_path = hasattr(replay, "write_staged") and __import__("os").environ.get("DRL_INGEST_FAST", "1") != "0"
         self._free: Deque[int] = deque(range(depth))
         self._staged: Deque[_Staged] = deque()          # thread -> service: copied into pinned memory
         self._retired: Deque[_Staged] = deque()         # slots retired, waiting for one more step launch
@@ -137,6 +141,11 @@ class AsyncIngest:
             out[name] = pin[off:off + nb].view(tdt).view(*shape)
         return out
 
+    def _tail_for(self, b: int, nbytes: int) -> torch.Tensor:
+        if self._tail[b].numel() < nbytes:
+            self._tail[b] = torch.zeros((nbytes + 4095) // 4096 * 4096, dtype=torch.uint8, device=self.device)
+        return self._tail[b]
+
     def service(self) -> int:
         """Advance every block by at most one stage; returns the number of items committed by this call. Call once per
         learner step, BEFORE launching the step."""
@@ -148,7 +157,8 @@ class AsyncIngest:
         # 3. commit the blocks whose DMA has finished (polled: the learner stream never waits for a copy)
         while self._copying and self._copying[0].done.query():
             rec = self._copying.popleft()
-            r.commit_block(rec.blk, self._prio[rec.buf])
+            pv = self._prio_view[rec.buf]
+            r.commit_block(rec.blk, pv if pv is not None else self._prio[rec.buf])
             with self._lock:
                 self._free.append(rec.buf)
             n_commit += rec.K
@@ -163,9 +173,13 @@ class AsyncIngest:
             with torch.cuda.stream(self.stream):
                 while self._retired and self._retired[0].retired_at < self._tick - 1:
                     rec = self._retired.popleft()
-                    v = self._views(rec)
-                    r.write_views(rec.blk, int(rec.meta["kind"]), v)     # plane pool / stacks / sequences: the replay knows
-                    self._prio[rec.buf][:rec.K].copy_(v["prio"], non_blocking=True)
+                    pv = r.write_staged(rec.blk, int(rec.meta["kind"]), self._bufs[rec.buf], rec.fields,
+                                        lambda nb, b=rec.buf: self._tail_for(b, nb)) if self.fast_path else None
+                    self._prio_view[rec.buf] = pv
+                    if pv is None:                                    # full-stack blocks: field by field
+                        v = self._views(rec)
+                        r.write_views(rec.blk, int(rec.meta["kind"]), v)     # plane pool / stacks / sequences: the replay knows
+                        self._prio[rec.buf][:rec.K].copy_(v["prio"], non_blocking=True)
                     rec.done = torch.cuda.Event()
                     rec.done.record(self.stream)
                     self._copying.append(rec)

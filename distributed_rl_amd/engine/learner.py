@@ -144,7 +144,11 @@ class HipLearner:
             # staging buffers in flight: a block lives ~7 learner steps between its retire and its commit (one more step
             # launch, the host's run-ahead, the DMA), so 4 buffers capped the ingest at ~0.5 blocks per learner step - at
             # 100 K transitions/s the actors of the system bench were waiting for ring slots
-            self.pipe = AsyncIngest(exp, self.replay, self.device, depth=int(os.environ.get("DRL_INGEST_DEPTH", "16")))
+            self.pipe = AsyncIngest(exp, self.replay, self.device, depth=int(os.environ.get("DRL_INGEST_DEPTH", "48")))
+            # shm register: also keep the two newest versions in a device double buffer that actors on THIS GPU read
+            # device to device (transport.ShmParams); rank 0 publishes, so only it exports one
+            if hasattr(params, "enable_device_mirror") and (dist is None or dist.rank == 0):
+                params.enable_device_mirror(self.device, self.engine.P.flat.numel() * 4)
             self._pub = _AsyncPublisher(self.engine.P.flat, params)
         if self.metrics is None:
             from ..obs import Metrics
@@ -283,6 +287,14 @@ class HipLearner:
         inflight = deque()
         dp = self.dist is not None and self.dist.enabled
         stop_period = int(os.environ.get("DRL_STOP_CHECK_STEPS", "200"))
+        # K learner steps per loop turn where the engine has them as ONE graph replay (ApexEngine.run_steps): a quarter of
+        # the launches, event records and ingest turns per step; everything a step needs from the one before it is on the
+        # device. Only where no periodic duty (metrics, checkpoint, the agreed stop of data-parallel ranks) falls inside.
+        K = int(getattr(self.engine, "steps_per_graph", 1)) if hasattr(self.engine, "run_steps") else 1
+        periods = [cfg.fit_timing, cfg.save_timing] + ([stop_period] if dp else [])
+
+        def clear_of_duties(t: int) -> bool:
+            return all((t % p == 0 and K <= p) or (t % p) + K <= p for p in periods)
         while end is None or self.step < end:
             if stop_event is not None:
                 # data-parallel ranks leave the loop TOGETHER (the step contains collectives): the request is agreed on
@@ -296,17 +308,22 @@ class HipLearner:
             ph = self.metrics_local.phase
             with ph("learner/ingest"):
                 self.ingest()
+            k = K if (K > 1 and (end is None or t + K <= end) and clear_of_duties(t)) else 1
             with ph("learner/step"):
-                self.engine.step()
+                if k > 1:
+                    self.engine.run_steps(k)
+                else:
+                    self.engine.step()
                 # bound the host's run-ahead: launches are asynchronous, and a loop that queues hundreds of graph replays
                 # ahead of the GPU makes everything ordered behind "now" on the learner stream (the ingest DMA's start
                 # event, a parameter snapshot, a stop request) wait for the whole queue
                 ev = torch.cuda.Event()
                 ev.record()
                 inflight.append(ev)
-                if len(inflight) > self.max_ahead:
+                if len(inflight) > (self.max_ahead if k == 1 else max(1, self.max_ahead - 1)):
                     inflight.popleft().synchronize()
-            if t % cfg.publish_period == 0 and time.time() - self._last_pub >= self.publish_interval:
+            pp = cfg.publish_period
+            if (t % pp == 0 or (t % pp) + k > pp) and time.time() - self._last_pub >= self.publish_interval:
                 with ph("learner/publish"):
                     self.publish()
             if t % cfg.fit_timing == 0:
@@ -326,7 +343,7 @@ class HipLearner:
             if t % cfg.save_timing == 0:
                 with ph("learner/save"):
                     self.save(save_model_dir)
-            self.step += 1
+            self.step += k
         torch.cuda.synchronize(self.device)
         return self.step
 

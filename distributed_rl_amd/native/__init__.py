@@ -75,6 +75,14 @@ def _declare_host(lib) -> None:
         "drl_param_version": (c_uint64, [c_void_p]),
         "drl_param_publish": (c_uint64, [c_void_p, c_void_p, c_uint64]),
         "drl_param_reset": (None, [c_void_p]),
+        "drl_param_nbytes": (c_uint64, [c_void_p, c_uint64]),
+        "drl_param_mirror_set": (None, [c_void_p, c_void_p, c_char_p, c_uint64, c_uint64]),
+        "drl_param_mirror_clear": (None, [c_void_p]),
+        "drl_param_mirror_get": (c_uint64, [c_void_p, c_void_p, c_void_p, u64p]),
+        "drl_param_mirror_begin": (None, [c_void_p, c_uint64]),
+        "drl_param_mirror_end": (None, [c_void_p, c_uint64]),
+        "drl_param_mirror_latest": (c_uint64, [c_void_p]),
+        "drl_param_mirror_check": (c_int, [c_void_p, c_uint64]),
         "drl_param_read": (c_uint64, [c_void_p, c_void_p, c_uint64, c_uint64, u64p]),
         "drl_beat_open": (c_void_p, [c_char_p, c_int]),
         "drl_beat_close": (None, [c_void_p, c_char_p]),

@@ -44,6 +44,15 @@ SIGS = {
     "drl_conv_halo_wprep": [P, P, P, P, P],
     "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
     "drl_halo_set_busy": [I, I],
+    # ingest.hip
+    "drl_ingest_scatter": [P, I, P, P, P, I, P, P, P, L, P],
+    # ipc_mirror.hip
+    "drl_ipc_alloc": [U, P, P],
+    "drl_ipc_free": [P],
+    "drl_ipc_open": [P, P],
+    "drl_ipc_close": [P],
+    "drl_copy_d2d_async": [P, P, U, P],
+    "drl_device_bus_id": [I, P],
     # conv_torso.hip
     "drl_torso_fwd": [P, P, I, P, P, P, I, I, P, I, P, P, P, I, I, P, P, P, P, P],
     "drl_torso_set_busy": [I],

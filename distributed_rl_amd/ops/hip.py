@@ -413,6 +413,24 @@ def conv_halo_fwd(layer: int, x1, f1: int, w1, b1, out1, x2=None, f2: int = 0, w
                                        _p(pw2), _p(pw3), _p(pwt2), _p(pwt3), _s()), "conv_halo_fwd")
 
 
+def ingest_scatter(tail: torch.Tensor, segs, wins, plane_base: int) -> None:
+    """One launch (ingest.hip) that scatters a staged experience block's tables out of ``tail`` (its device copy, uint8):
+    segs = [(byte offset in tail, dst tensor of 32-bit elements, element count)], wins = [(byte offset of an int32 plane
+    index table, dst int64 tensor, count)]: dst[i] = (src[i] + plane_base) * 7056."""
+    ns, nw = len(segs), len(wins)
+    assert ns <= 8 and nw <= 2 and tail.dtype == torch.uint8 and tail.is_cuda
+    for off, dst, n in segs:
+        assert dst.element_size() == 4 and dst.is_contiguous() and dst.numel() >= n and off + 4 * n <= tail.numel()
+    for off, dst, n in wins:
+        assert dst.dtype == torch.int64 and dst.is_contiguous() and dst.numel() >= n and off + 4 * n <= tail.numel()
+    LL, VP, CI = ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int
+    _ck(native.hip().drl_ingest_scatter(
+        _p(tail), ns, (LL * max(ns, 1))(*[s[0] for s in segs]), (VP * max(ns, 1))(*[s[1].data_ptr() for s in segs]),
+        (CI * max(ns, 1))(*[s[2] for s in segs]), nw, (LL * max(nw, 1))(*[w[0] for w in wins]),
+        (VP * max(nw, 1))(*[w[1].data_ptr() for w in wins]), (CI * max(nw, 1))(*[w[2] for w in wins]), int(plane_base), _s()),
+        "ingest_scatter")
+
+
 class TorsoNet:
     """One network's operands of the fused torso forward (``torso_fwd``): plane-store byte offsets (None = dense HWC
     stacks), frame count, the three conv weights (bf16; conv1 in the input form's k order) and biases (fp32), act3 out,

@@ -161,6 +161,29 @@ class DevicePER(RingPair):
         from ..transport import codec
         return (K, M) if kind == codec.KIND_APEX_PLANES else (K, 2 * STACK * K)
 
+    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for) -> Optional[torch.Tensor]:
+        """The ingest pipeline's write of a plane-pool block straight out of its pinned staging buffer ``pin`` (fields =
+        codec.layout): ONE DMA puts the planes into the ring, ONE DMA brings the tables (everything behind the planes) into
+        the device buffer ``tail_for(nbytes)``, ONE launch scatters them (window offsets, actions, rewards, dones). Returns the
+        block's priorities as a device view of that buffer (for ``commit_block``), or None for a block kind it does not
+        take (the caller falls back to ``write_views``)."""
+        from ..transport import codec
+        if kind != codec.KIND_APEX_PLANES:
+            return None
+        f = {name: (off, nb) for name, _, _, off, nb in fields}
+        s, K, p, M = blk.slot, blk.K, blk.plane, blk.M
+        p_off, p_nb = f["planes"]
+        assert p_nb == M * PLANE_BYTES
+        self.frames[p:p + M].view(-1).copy_(pin[p_off:p_off + p_nb], non_blocking=True)
+        t0, t1 = f["win_s"][0], f["prio"][0] + f["prio"][1]
+        tail = tail_for(t1 - t0)
+        tail[:t1 - t0].copy_(pin[t0:t1], non_blocking=True)
+        o = lambda name: f[name][0] - t0                                            # noqa: E731
+        cap = self.capacity
+        H.ingest_scatter(tail, [(o("action"), self.act[s:s + K], K), (o("reward"), self.rew[s:s + K], K), (o("done"), self.done[s:s + K], K)],
+                         [(o("win_s"), self.win[s:s + K], K), (o("win_s2"), self.win[cap + s:cap + s + K], K)], p)
+        return tail[o("prio"):o("prio") + 4 * K].view(torch.float32)
+
     def write_views(self, blk: _Block, kind: int, v) -> None:
         from ..transport import codec
         if kind == codec.KIND_APEX_PLANES:

@@ -176,6 +176,28 @@ class DeviceSequenceReplay(RingPair):
             return K, self.stack_block_planes(views["frames"], views["length"])
         return K, K * STACK * self.T
 
+    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for) -> Optional[torch.Tensor]:
+        """As DevicePER.write_staged, for sequence blocks with a plane pool (codec kind 4): planes by one DMA, the tables by
+        one DMA + one scatter launch; returns the priorities as a device view, None for other block kinds."""
+        from ..transport import codec
+        if kind != codec.KIND_R2D2_PLANES:
+            return None
+        f = {name: (off, nb) for name, _, _, off, nb in fields}
+        s, K, p, M, T = blk.slot, blk.K, blk.plane, blk.M, self.T
+        p_off, p_nb = f["planes"]
+        assert p_nb == M * PLANE_BYTES and f["win"][1] == 4 * K * T
+        self.frames[p:p + M].view(-1).copy_(pin[p_off:p_off + p_nb], non_blocking=True)
+        t0, t1 = f["win"][0], f["prio"][0] + f["prio"][1]
+        tail = tail_for(t1 - t0)
+        tail[:t1 - t0].copy_(pin[t0:t1], non_blocking=True)
+        o = lambda name: f[name][0] - t0                                            # noqa: E731
+        Hd = self.h0.shape[1]
+        H.ingest_scatter(tail, [(o("action"), self.act[s:s + K], K * T), (o("reward"), self.rew[s:s + K], K * T),
+                                (o("done"), self.done[s:s + K], K * T), (o("length"), self.length[s:s + K], K),
+                                (o("h0"), self.h0[s:s + K], K * Hd), (o("c0"), self.c0[s:s + K], K * Hd)],
+                         [(o("win"), self.win[s:s + K], K * T)], p)
+        return tail[o("prio"):o("prio") + 4 * K].view(torch.float32)
+
     def write_views(self, blk: _Block, kind: int, v) -> None:
         from ..transport import codec
         if kind == codec.KIND_R2D2_PLANES:

@@ -217,7 +217,10 @@ class Actor:
         # a device engine takes the parameters as a tensor: channels that receive on the GPU (collective broadcast over
         # RCCL) hand it over without a round trip through host memory
         pull = getattr(self.params, "pull_tensor", None) if self.engine is not None else None
-        got = pull(self._version) if pull is not None else self.params.pull(self._version)
+        if pull is not None and getattr(self.params, "device_mirror", False):
+            got = pull(self._version, self.device)           # shm register: D2D out of the learner's mirror when it is on our GPU
+        else:
+            got = pull(self._version) if pull is not None else self.params.pull(self._version)
         if got is None:
             return False
         self._version, flat = got

@@ -135,6 +135,9 @@ def actor_main(argv=None) -> int:
         par.close()
         par = _actor_lane(world, _flat_numel(args.algorithm, env.n_action), device)
     if device.type == 'cuda':
+        # an explicit index from here on ("cuda" alone = the current device): set_device and the IPC-mapped parameter mirror
+        # (transport.ShmParams) need one
+        device = torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
         torch.cuda.set_device(device)
     hb = _heartbeat(args, "actor", args.no)
     if args.algorithm == 'ape_x':

@@ -93,6 +93,10 @@ def main(argv=None) -> int:
         """Marks the start and the end of the measurement window while the learner loop runs in the main thread."""
         t_begin = time.time()
         while learner.step < 5 and time.time() - t_begin < 240:      # learn-start reached + graph captured
+            if any(p.poll() is not None for p in procs):             # an actor died: no point in waiting for its experience
+                marks["dead"] = True
+                stop.set()
+                return
             time.sleep(0.05)
         time.sleep(args.warmup_seconds)
         marks["a"] = (time.time(), learner.step, learner.ingested, actor_steps(), exp.stats())
@@ -107,6 +111,8 @@ def main(argv=None) -> int:
     try:
         learner.optimize_loop(save_model_dir=os.path.join(log_dir, "models"), stop_event=stop, warmup_timeout=240)
         th.join(5)
+        if marks.get("dead"):
+            raise RuntimeError("an actor process exited during start-up")
         learner.engine.stats()                               # raises if a bounded in-kernel wait timed out
         (ta, sa, ia, ea, ra), (tb, sb, ib, eb, rb) = marks["a"], marks["b"]
         dt = tb - ta

@@ -2,6 +2,7 @@
 checkpoint in the reference format + resume; ActorEngine actions / priorities vs the PyTorch oracle."""
 import glob
 import os
+import time
 
 import numpy as np
 import pytest
@@ -291,3 +292,66 @@ def test_collective_param_lane_takes_the_device_snapshot_over_rccl(tmp_path):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print("device-to-device parameter publication over RCCL (world 1):", out)
     assert out["ok"]
+
+
+_MIRROR_READER = r"""
+import sys, time, json
+import torch
+from distributed_rl_amd.transport import ShmParams
+name, n_versions = sys.argv[1], int(sys.argv[2])
+par = ShmParams(name, create=False)
+dev = torch.device("cuda")
+have, seen, bad = 0, [], 0
+t0 = time.time()
+while len(seen) < n_versions and time.time() - t0 < 60:
+    got = par.pull_tensor(have, dev)
+    if got is None:
+        time.sleep(0.002)
+        continue
+    have, flat = got
+    flat = torch.as_tensor(flat)
+    # every published version v is the constant vector v: a torn copy would mix two values
+    if not bool((flat == float(have)).all()):
+        bad += 1
+    seen.append(have)
+print(json.dumps(dict(seen=seen, bad=bad, mirror=par.mirror_pulls, host=par.host_pulls)), flush=True)
+par.close()
+"""
+
+
+def test_param_register_device_mirror_between_processes(run_id):
+    """The learner's parameter versions reach an actor PROCESS on the same GPU device to device: the reader's pulls all
+    come out of the IPC-mapped double buffer (none through the host register), whole (never a mix of two versions), with
+    increasing version numbers; with the mirror switched off the same reader falls back to the host register."""
+    import json
+    import subprocess
+    import sys
+    from distributed_rl_amd.transport import ShmParams, shm_names
+    name = shm_names(run_id)[1]
+    par = ShmParams(name, create=True, capacity=16 << 20)
+    n = 3_300_000
+    try:
+        assert par.enable_device_mirror("cuda", n * 4)
+        for env_extra, want_mirror in (({}, True), ({"DRL_PARAM_MIRROR": "0"}, False)):
+            par.reset()
+            env = dict(os.environ, PYTHONPATH=os.getcwd(), **env_extra)
+            proc = subprocess.Popen([sys.executable, "-c", _MIRROR_READER, name, "5"], stdout=subprocess.PIPE, env=env, text=True)
+            snap = torch.empty(n, device="cuda")
+            host = np.empty(n, np.float32)
+            t0 = time.time()
+            v = 0
+            while proc.poll() is None and time.time() - t0 < 90:
+                v += 1
+                snap.fill_(float(v)); host.fill(float(v))
+                torch.cuda.synchronize()
+                assert par.publish2(host, snap) == v
+                time.sleep(0.01)
+            out = json.loads(proc.stdout.read().strip().splitlines()[-1])
+            assert proc.returncode == 0 and out["bad"] == 0 and len(out["seen"]) == 5, out
+            assert out["seen"] == sorted(set(out["seen"]))
+            if want_mirror:
+                assert out["mirror"] == 5 and out["host"] == 0, out
+            else:
+                assert out["mirror"] == 0 and out["host"] == 5, out
+    finally:
+        par.close()
