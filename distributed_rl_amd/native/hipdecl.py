@@ -44,6 +44,9 @@ SIGS = {
     "drl_conv_halo_wprep": [P, P, P, P, P],
     "drl_conv_halo_dgrad": [I, P, I, P, P, P, P],
     "drl_halo_set_busy": [I, I],
+    # pingpong.hip
+    "drl_pingpong": [I, I, I, I, I, I, P, P],
+    "drl_allgather_bench": [I, I, I, I, I, P, P],
     # ingest.hip
     "drl_ingest_scatter": [P, I, P, P, P, I, P, P, P, L, P],
     # ipc_mirror.hip
