@@ -25,6 +25,13 @@ from ..models import DuelingDQN, DuelingLSTMDQN
 from ..transport import ExperienceChannel, ParamChannel
 
 
+# exit status of a learner process whose step guard fired (engine/guard.py: a bounded in-kernel wait timed out, the step was
+# discarded, parameters / optimizer moments / priorities are intact): EX_TEMPFAIL. The launcher restarts the learner from
+# the checkpoint written on the way out, with the path that timed out switched off (runtime/launcher.py heal_learner).
+EXIT_GUARD = 75
+FAULT_NOTE = "learner_fault.json"
+
+
 class _AsyncPublisher:
     """Parameter publication off the learner's critical path: ``publish()`` snapshots the flat fp32 parameters with one
     D2D copy on the learner stream (a consistent version, ~10 us); a side stream takes it from there and a thread hands
@@ -109,13 +116,15 @@ class _AsyncPublisher:
 class HipLearner:
     def __init__(self, algorithm: str, n_action: int, cfg, exp: ExperienceChannel, params: ParamChannel, metrics=None,
                  replay_size: int = 100_000, device="cuda", heartbeat=None, dist=None, use_graph: bool = True,
-                 publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0, save_replay: bool = False):
+                 publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0, save_replay: bool = False,
+                 reset_channels: bool = True):
         self.algorithm, self.cfg = algorithm, cfg
         self.exp, self.params, self.metrics, self.heartbeat, self.dist = exp, params, metrics, heartbeat, dist
         self.device = torch.device(device)
         self.is_r2d2 = algorithm == "r2d2"
-        self.params.reset()
-        self.exp.reset()
+        if reset_channels:                   # DEL params / DEL experience (ape_x/learner.py:37, replay.py:21)
+            self.params.reset()
+            self.exp.reset()                 # (a learner that takes over a running system keeps both: parameter versions go on)
         replay_size = self._fit_capacity(replay_size, cfg)
         if self.is_r2d2:
             from ..replay.device_seq import DeviceSequenceReplay
@@ -365,7 +374,8 @@ def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=Non
     torch.distributed.run's environment); None = a single learner."""
     seed_ = (args.seed or 0) + (dist.rank if dist is not None else 0)      # every shard samples its own stream
     learner = HipLearner(args.algorithm, n_action, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb, dist=dist,
-                         seed=seed_, save_replay=getattr(args, "save_replay", False))
+                         seed=seed_, save_replay=getattr(args, "save_replay", False),
+                         reset_channels=not getattr(args, "attach", False))
     if dist is not None:                                                   # identical initial weights on every rank
         dist.broadcast_flat(learner.engine.P.flat)
         from ..ops import hip as H
@@ -382,10 +392,36 @@ def run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=Non
         signal.signal(signal.SIGTERM, lambda *_: stop.set())
     except ValueError:                                                     # not the main thread (tests)
         pass
+    rc = 0
     try:
         learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir, stop_event=stop)
     except KeyboardInterrupt:
         pass
+    except RuntimeError as e:
+        if "discarded" not in str(e):
+            raise
+        rc = _guard_exit(learner, args.save_dir, e)
     finally:
         learner.close()
-    return 0
+    return rc
+
+
+def _guard_exit(learner: "HipLearner", save_dir: str, err: BaseException) -> int:
+    """The step guard fired: the poisoned step was discarded on the device (engine/guard.py), so what is in HBM is the state
+    after the last good step. Write it out, leave a note that names the path that timed out, and return EXIT_GUARD."""
+    import json
+    import sys
+    print("[learner] %s" % err, file=sys.stderr, flush=True)
+    note = {"step": learner.step, "error": str(err)[:500], "checkpoint": None}
+    try:
+        torch.cuda.synchronize(learner.device)
+        note["checkpoint"] = learner.save(save_dir)
+    except Exception as e2:  # noqa: BLE001 - the note still says what happened; the launcher falls back to an older checkpoint
+        note["save_error"] = repr(e2)[:300]
+    try:
+        os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, FAULT_NOTE), "w") as fh:
+            json.dump(note, fh)
+    except OSError:
+        pass
+    return EXIT_GUARD

@@ -301,6 +301,8 @@ class R2D2Engine(ShardedIS):
         self.use_graph = use_graph
         self.fj = ForkJoin(dev, 3, overlap)               # target forward / weight gradients on side streams
         self.persistent_lstm = H.lstm_seq_supported(B, Hd) and os.environ.get("DRL_PERSISTENT_LSTM", "1") != "0"
+        if os.environ.get("DRL_LSTM_SPIN_LIMIT"):        # fault injection (tests of the self-healing launcher): polls give up early
+            H.lstm_set_spin_limit(int(os.environ["DRL_LSTM_SPIN_LIMIT"]))
         self._graphs = None
         self.steps_done = 0
         # bounded inter-workgroup / inter-GPU waits of this step: when one gives up the step is discarded (engine/guard.py)

@@ -87,6 +87,54 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
+EXIT_GUARD = 75          # engine/learner.py: the learner's step guard fired, state saved, restart me without that path
+# which switch turns off the path a fired guard names (engine/guard.py names; engine/r2d2.py, parallel/dist.py switches)
+HEAL_SWITCHES = (("persistent LSTM", "DRL_PERSISTENT_LSTM"), ("persistent BPTT", "DRL_PERSISTENT_BPTT"),
+                 ("xGMI", "DRL_XGMI_AR"))
+
+
+def newest_checkpoint(save_dir: str) -> str:
+    """``model_<t>.pth`` with the largest t in ``save_dir`` ('' if none)."""
+    import glob
+    import re
+    best, best_t = "", -1
+    for f in glob.glob(os.path.join(save_dir, "model_*.pth")):
+        m = re.fullmatch(r"model_(\d+)\.pth", os.path.basename(f))
+        if m and int(m.group(1)) > best_t:
+            best, best_t = f, int(m.group(1))
+    return best
+
+
+def heal_learner(cmd: List[str], env: Dict[str, str], save_dir: str):
+    """What to start in place of a learner that left with EXIT_GUARD: the same command, attached to the live segments
+    (``--attach``: the actors keep running and keep their parameter versions), resumed from the checkpoint the dying learner
+    wrote (or the newest older one), with every path named in its fault note switched off. Returns (cmd, env, reason)."""
+    import json
+    note = {}
+    try:
+        with open(os.path.join(save_dir, "learner_fault.json")) as fh:
+            note = json.load(fh)
+    except (OSError, ValueError):
+        pass
+    err = str(note.get("error", ""))
+    off = {var: "0" for key, var in HEAL_SWITCHES if key in err}
+    if not off:                                   # no note / an unknown guard: every bounded-wait path off
+        off = {var: "0" for _, var in HEAL_SWITCHES}
+    ckpt = note.get("checkpoint") or ""
+    if not (ckpt and os.path.exists(ckpt)):
+        ckpt = newest_checkpoint(save_dir)
+    new = [a for a in cmd]
+    if "--resume" in new:                         # replace an older --resume
+        i = new.index("--resume")
+        del new[i:i + 2]
+    if "--attach" not in new:
+        new.append("--attach")
+    if ckpt:
+        new += ["--resume", ckpt]
+    return new, dict(env, **off), "guard fired (%s): restarting from %s with %s" % (
+        err[:120] or "no fault note", ckpt or "scratch", " ".join("%s=0" % v for v in sorted(off)))
+
+
 def _free_beats(hb_table, name: str, pid: int) -> None:
     """Heartbeat rows of a reaped child (every learner rank is a child of its own)."""
     if hb_table is None:
@@ -107,6 +155,10 @@ def main(argv=None) -> int:
     ap.add_argument("--learner-args", type=str, default="", help="extra flags for learner_node.py (one string)")
     ap.add_argument("--actor-args", type=str, default="", help="extra flags for actor_node.py (one string)")
     ap.add_argument("--timeout", type=float, default=0.0, help="stop everything after this many seconds (0 = never)")
+    ap.add_argument("--no-heal-learner", action="store_true",
+                    help="a learner whose step guard fired (exit status 75) ends the run instead of being restarted from its "
+                         "last checkpoint with the path that timed out switched off")
+    ap.add_argument("--max-heals", type=int, default=3)
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--gpus", type=int, default=-1, help="GPUs to place processes on (-1 = all visible; 0 = CPU only)")
     args = ap.parse_args(argv)
@@ -142,6 +194,13 @@ def main(argv=None) -> int:
 
     def spawn(name):
         procs[name] = subprocess.Popen(cmds[name], env=dict(env, **extra_env.get(name, {})), cwd=ROOT)
+
+    def learner_save_dir() -> str:
+        la = args.learner_args.split()
+        d = la[la.index("--save-dir") + 1] if "--save-dir" in la and la.index("--save-dir") + 1 < len(la) else "./models"
+        return d if os.path.isabs(d) else os.path.join(ROOT, d)
+
+    heals = {"n": 0}
 
     def teardown():
         for p in procs.values():
@@ -187,6 +246,16 @@ def main(argv=None) -> int:
                 if code is None:
                     continue
                 _free_beats(hb_table, name, p.pid)       # a killed child could not unregister its heartbeat slot
+                if (code == EXIT_GUARD and name == "learner" and plan.n_learners == 1 and not plan.lanes
+                        and not args.no_heal_learner and heals["n"] < args.max_heals and not stop["flag"]):
+                    # self-healing: the learner discarded a step whose bounded in-kernel wait timed out, saved its state
+                    # and left; a fresh process takes over the live segments, the actors never notice
+                    cmds[name], new_env, why = heal_learner(cmds[name], extra_env.get(name, {}), learner_save_dir())
+                    extra_env[name] = new_env
+                    heals["n"] += 1
+                    print("[launcher] learner %s (heal %d of %d)" % (why, heals["n"], args.max_heals), flush=True)
+                    spawn(name)
+                    continue
                 if name in restartable and args.restart_actors and not stop["flag"]:
                     print("[launcher] %s exited with %s, restarting" % (name, code), flush=True)
                     spawn(name)

@@ -70,7 +70,7 @@ def load_checkpoint(path: str, policy, target=None, optimizer=None) -> int:
 class Learner:
     def __init__(self, policy_net, target_net, optimizer, cfg, exp: ExperienceChannel, params: ParamChannel,
                  metrics=None, replay_size: Optional[int] = None, device=torch.device("cpu"),
-                 heartbeat=None, memory=None, dist=None, sync_target: bool = True):
+                 heartbeat=None, memory=None, dist=None, sync_target: bool = True, reset_channels: bool = True):
         self.policy, self.target, self.opt, self.cfg = policy_net, target_net, optimizer, cfg
         if sync_target:
             self.target.load_state_dict(self.policy.state_dict())    # learner.py:33-34
@@ -80,8 +80,9 @@ class Learner:
         self.heartbeat = heartbeat
         self.dist = dist
         self.is_r2d2 = isinstance(cfg, R2D2Config)
-        self.params.reset()                                           # DEL params (learner.py:37)
-        self.exp.reset()                                              # DEL experience (replay.py:21)
+        if reset_channels:               # (a learner restarted next to running actors, --attach, keeps both)
+            self.params.reset()                                       # DEL params (learner.py:37)
+            self.exp.reset()                                          # DEL experience (replay.py:21)
         self.replay = Replay(replay_size or cfg.replay_size, exp, memory=memory)
         self.replay.start()
         self._pack = ParamPack.from_module(self.policy)
@@ -161,6 +162,12 @@ class Learner:
             if stop_event is not None and stop_event.is_set():
                 break
             t = self.step
+            # fault injection for the self-healing launcher's test (no bounded in-kernel waits on this engine): behave like
+            # the GPU learner whose persistent LSTM kernel timed out - until that path is "switched off"
+            inj = os.environ.get("DRL_INJECT_GUARD_AT_STEP")
+            if inj and t == start_step + int(inj) and os.environ.get("DRL_PERSISTENT_LSTM", "1") != "0":
+                raise RuntimeError("learner step discarded: a bounded in-kernel wait timed out (persistent LSTM (online)); "
+                                   "injected by DRL_INJECT_GUARD_AT_STEP")
             loss = self.train_step()
             if t % cfg.publish_period == 0:
                 self.publish()                                                                  # learner.py:83

@@ -192,6 +192,9 @@ def learner_main(argv=None) -> int:
     parser.add_argument('--register-actors', type=int, default=-1,
                         help="number of this shard's actors that read the parameter register (-1 = unknown: keep publishing "
                              "to it); 0 lets a learner whose actors are all on broadcast lanes skip the host copy.")
+    parser.add_argument('--attach', action='store_true',
+                        help="take over the EXISTING experience ring / parameter register of --run-id instead of creating fresh "
+                             "ones: a learner restarted by the launcher (self-healing) next to actors that keep running.")
     parser.add_argument('--ring-slots', type=int, default=64)
     parser.add_argument('--ring-slot-mb', type=int, default=8)
     _common(parser)
@@ -215,7 +218,7 @@ def learner_main(argv=None) -> int:
             device = torch.device("cuda", lr_)
     metrics = make_metrics("learner" if rank == 0 else "learner_r%d" % rank, args.visdomserver, args.log_dir,
                            args.quiet or rank > 0)
-    exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=True, host=args.redisserver,
+    exp, par = connect(args.transport, shard_run_id(args.run_id, rank, world), create=not args.attach, host=args.redisserver,
                        n_slots=args.ring_slots, slot_bytes=args.ring_slot_mb << 20)
     register = None
     dist = None
@@ -244,8 +247,14 @@ def learner_main(argv=None) -> int:
         engine = 'hip' if device.type == 'cuda' else 'torch'
     try:
         if engine == 'hip':
-            from ..engine.learner import run_hip_learner
-            return run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=dist)
+            from ..engine.learner import EXIT_GUARD, run_hip_learner
+            rc = run_hip_learner(args, cfg, n_action, exp, par, metrics, hb, device, dist=dist)
+            if rc == EXIT_GUARD:
+                # the launcher starts a fresh learner that ATTACHES to these segments (actors keep running): leave them in place
+                for ch in (exp, par, register):
+                    if ch is not None and hasattr(ch, "_owner"):
+                        ch._owner = False
+            return rc
         from .learner import Learner, load_checkpoint
         if args.algorithm == 'ape_x':
             model, target = DuelingDQN(n_action).to(device), DuelingDQN(n_action).to(device)
@@ -261,12 +270,27 @@ def learner_main(argv=None) -> int:
                     dist.broadcast_flat(p_.data)
                 target.load_state_dict(model.state_dict())
         learner = Learner(model, target, opt, cfg, exp, par, metrics, args.replaysize, device, heartbeat=hb,
-                          sync_target=not args.resume, dist=dist)
+                          sync_target=not args.resume, dist=dist, reset_channels=not args.attach)
         learner.publish()
         try:
             learner.optimize_loop(max_steps=args.max_steps, save_model_dir=args.save_dir, start_step=start)
         except KeyboardInterrupt:
             pass
+        except RuntimeError as e:
+            if "discarded" not in str(e):
+                raise
+            # same contract as the GPU learner (engine/learner.py _guard_exit): state out, note, EXIT_GUARD; the segments stay
+            import json
+            from ..engine.learner import EXIT_GUARD, FAULT_NOTE
+            from .learner import save_checkpoint
+            print("[learner] %s" % e, file=sys.stderr, flush=True)
+            ck = save_checkpoint(args.save_dir, learner.step, model, target, opt)
+            with open(os.path.join(args.save_dir, FAULT_NOTE), "w") as fh:
+                json.dump({"step": learner.step, "error": str(e)[:500], "checkpoint": ck}, fh)
+            for ch in (exp, par, register):
+                if ch is not None and hasattr(ch, "_owner"):
+                    ch._owner = False
+            return EXIT_GUARD
         finally:
             learner.close()
     finally:

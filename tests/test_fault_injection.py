@@ -157,3 +157,50 @@ def test_sigstop_actor_is_killed_as_stalled_and_restarted(tmp_path, run_id):
     assert re.search(r"actor_1 exited with -?\d+, restarting", out), out[-3000:]
     assert new_pid != pid
     assert "learner exited with 0" in out and rc == 0, out[-3000:]
+
+
+def test_heal_command_from_fault_note(tmp_path):
+    """What the launcher starts in place of a learner that left with status 75: attached, resumed from the checkpoint the note
+    names (or the newest one), the paths the fired guards name switched off (all of them when there is no note)."""
+    import json
+    from distributed_rl_amd.runtime.launcher import heal_learner, newest_checkpoint
+    d = str(tmp_path)
+    for t in (0, 10000, 200):
+        open(os.path.join(d, "model_%d.pth" % t), "w").close()
+    open(os.path.join(d, "model_200.aux.pth"), "w").close()
+    assert newest_checkpoint(d).endswith("model_10000.pth")
+    cmd, env, why = heal_learner(["python", "learner_node.py", "--resume", "old.pth", "-a", "r2d2"], {"A": "1"}, d)
+    assert cmd[-3:] == ["--attach", "--resume", os.path.join(d, "model_10000.pth")] and "old.pth" not in cmd
+    assert env == {"A": "1", "DRL_PERSISTENT_LSTM": "0", "DRL_PERSISTENT_BPTT": "0", "DRL_XGMI_AR": "0"}
+    json.dump({"error": "learner step discarded: a bounded in-kernel wait timed out (direct xGMI all-reduce)",
+               "checkpoint": os.path.join(d, "model_200.pth")}, open(os.path.join(d, "learner_fault.json"), "w"))
+    cmd, env, why = heal_learner(["python", "learner_node.py"], {}, d)
+    assert cmd[-1].endswith("model_200.pth") and env == {"DRL_XGMI_AR": "0"} and "xGMI" in why
+
+
+def test_learner_whose_guard_fired_is_restarted_from_its_checkpoint_next_to_running_actors(tmp_path, run_id):
+    """Self-healing: the learner's step guard fires at its 10th step (injected; on a GPU it is a persistent
+    kernel's bounded wait), it writes its state + a fault note and leaves with status 75; the launcher starts a fresh learner
+    that ATTACHES to the live ring / register with the offending path switched off and resumes from that checkpoint. The
+    actors are never restarted and the run ends with the healed learner's exit status 0."""
+    os.environ["DRL_INJECT_GUARD_AT_STEP"] = "10"
+    try:
+        p, lines, th = _launch(run_id, tmp_path, [], learner_steps=40)
+    finally:
+        del os.environ["DRL_INJECT_GUARD_AT_STEP"]
+    try:
+        pid_before = _actor_pid(run_id, 1)
+        rc = p.wait(timeout=300)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    th.join(10)
+    out = "".join(lines)
+    assert re.search(r"learner guard fired .*persistent LSTM.*restarting from .*model_10\.pth with DRL_PERSISTENT_LSTM=0 \(heal 1 of 3\)",
+                     out), out[-3000:]
+    assert "learner exited with 0" in out and rc == 0, out[-3000:]
+    assert not re.search(r"actor_\d exited with .*restarting", out), out[-3000:]
+    import glob
+    saved = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / "models" / "model_*.pth")) if ".aux" not in f)
+    assert "model_10.pth" in saved and os.path.exists(str(tmp_path / "models" / "learner_fault.json"))
+    assert pid_before > 0

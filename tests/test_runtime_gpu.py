@@ -355,3 +355,26 @@ def test_param_register_device_mirror_between_processes(run_id):
                 assert out["mirror"] == 0 and out["host"] == 5, out
     finally:
         par.close()
+
+
+def test_launcher_heals_a_learner_whose_persistent_kernel_timed_out(tmp_path, run_id):
+    """The real thing behind tests/test_fault_injection.py's injected version: every inter-workgroup poll of the persistent
+    LSTM kernels gives up at once (DRL_LSTM_SPIN_LIMIT=0), the R2D2 learner's step guard discards the step, the process
+    writes its checkpoint + fault note and leaves with status 75; the launcher restarts it ATTACHED to the live segments with
+    the persistent paths switched off, and that learner finishes its step budget next to the same actor process."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    save = tmp_path / "models"
+    env = dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="2", DRL_LSTM_SPIN_LIMIT="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-u", "-m", "distributed_rl_amd.runtime.launcher", "--num-actors", "1", "--conf", "config/all_r2d2.conf",
+           "--run-id", run_id, "--timeout", "200",
+           "--learner-args", "--max-steps 6 --batch-size 16 --start-memory-size 32 --save-timing 100000 --save-dir %s --quiet "
+                             "--env SyntheticCatch-v0 -s 256" % save,
+           "--actor-args", "--quiet --env SyntheticCatch-v0 --num-envs 16"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    out = r.stdout + r.stderr
+    assert re.search(r"learner guard fired .*persistent.*with .*DRL_PERSISTENT_LSTM=0.*\(heal 1 of 3\)", out), out[-4000:]
+    assert "learner exited with 0" in out and r.returncode == 0, out[-4000:]
+    assert not re.search(r"actor_1 exited", out.split("learner exited with 0")[0]), out[-4000:]
