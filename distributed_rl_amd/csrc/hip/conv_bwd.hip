@@ -13,24 +13,8 @@ __global__ __launch_bounds__(256) void k_colsum(const bf16_t* __restrict__ dy, l
     colsum_block(dy, total, NC8, cpb, db, blockIdx.x, red);
 }
 
-// out[r][c] = a[r][c] * (mask[r][c] > 0)   (standalone ReLU backward, bf16)
-__global__ __launch_bounds__(256) void k_relu_mask(const bf16_t* __restrict__ a, const bf16_t* __restrict__ mask,
-                                                  bf16_t* __restrict__ out, long long n8) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
-        uint4 v = reinterpret_cast<const uint4*>(a)[i], m = reinterpret_cast<const uint4*>(mask)[i];
-        uint32_t vw[4] = {v.x, v.y, v.z, v.w}, mw[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            uint32_t lo = mw[t] & 0xffffu, hi = mw[t] >> 16, keep = 0;
-            if (lo != 0 && !(lo & 0x8000u)) keep |= 0xffffu;
-            if (hi != 0 && !(hi & 0x8000u)) keep |= 0xffff0000u;
-            vw[t] &= keep;
-        }
-        reinterpret_cast<uint4*>(out)[i] = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-    }
-}
 
-static int grid1d(long long n) {
+[[maybe_unused]] static int grid1d(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
@@ -43,8 +27,3 @@ DRL_API int drl_colsum(const void* dy, int M, int N, float* db, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-DRL_API int drl_relu_mask(const void* a, const void* mask, void* out, long long n, hipStream_t s) {
-    if (n <= 0 || n % 8) return -1;
-    k_relu_mask<<<grid1d(n / 8), 256, 0, s>>>((const bf16_t*)a, (const bf16_t*)mask, (bf16_t*)out, n / 8);
-    return (int)hipGetLastError();
-}

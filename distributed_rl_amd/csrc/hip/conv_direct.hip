@@ -32,19 +32,13 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint2 v) {
     return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
 }
 
-// conv1 in f16 instead of bf16 (DRL_CONV1_F16): the kernel is vector-issue bound (59 % of its wave cycles wait for an
+// conv1 in f16 instead of bf16: the kernel is vector-issue bound (59 % of its wave cycles wait for an
 // instruction slot) and most of its vector work is the u8 -> bf16 conversion: 12 instructions per 8 pixels. In f16 the
 // conversion is ONE v_perm_b32 per 2 pixels: the half 0x6400 | b is exactly 1024 + b (ulp 1 at 2^10), so a byte next to a
 // constant 0x64 byte already is a usable operand. The accumulators start at -1024 * sum_k w[n][k], which cancels the
 // offset exactly up to fp32 rounding at |1024 * sum w| ~ 1e3 (1e-4 pixel units, 5e-7 after the /255). The weights are
 // converted bf16 -> f16 once per wave (exact: |w| < 65504, f16 has more mantissa bits; |w| < 6e-5 goes denormal).
-#ifndef DRL_CONV1_F16
-#define DRL_CONV1_F16 1
-#endif
-#ifndef DRL_CONV1_WAVES_PER_CU
-#define DRL_CONV1_WAVES_PER_CU 8     // wave slots the tiles are dealt to (per CU): fewer waves = fewer weight set-ups
-#endif
-static int g_conv1_waves = DRL_CONV1_WAVES_PER_CU;   // host side; drl_conv1_set_waves: tuning hook
+static int g_conv1_waves = 8;   // wave slots the tiles are dealt to (per CU): fewer waves = fewer weight set-ups; drl_conv1_set_waves
 // ---------------------------------------------------------------------------------------------------------------
 // conv1: u8 frames -> bf16 [n,20,20,32]. Two input forms:
 //   dense (OFF = false):  [n,84,84,4] HWC stacks as the environments deliver them (actors); weights [32][kh][kw][c].
@@ -71,7 +65,6 @@ struct Conv1Net {
 // two-network launch below and is gone.)
 template <bool OFF, int PAIR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_conv1_direct(const uint8_t* __restrict__ x, Conv1Net n1, Conv1Net n2, Conv1Net n3, int nblk1) {
-    static_assert(!PAIR || DRL_CONV1_F16, "the two-weight-set form exists for the f16 path only");
     const bool second = PAIR != 1 && (int)blockIdx.x >= nblk1;         // block-uniform
     constexpr bool pair_blk = PAIR == 1;
     const long long* __restrict__ frame_off = second ? n2.frame_off : n1.frame_off;
@@ -85,7 +78,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // every wave owns `per` CONSECUTIVE 16-row tiles (neighbouring output pixels overlap in the input: L1/L2 hits)
     const int t0 = (blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * per, t1 = min(ntiles, t0 + per);   // SGPRs
     if (t0 >= ntiles) return;                       // wave-uniform: no barriers in this kernel
-#if DRL_CONV1_F16
     uint4 wf[2][8];
     float acc0[2][4];                               // accumulator start: -1024 * (sum over k of this lane's channels' weights)
     {
@@ -122,14 +114,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int i = 0; i < 4; ++i) acc0b[t][i] = -1024.0f * __shfl(csum[t], g * 4 + i, WAVE);
         }
     }
-#else
-    bf16x8 wf[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            wf[t][s] = *reinterpret_cast<const bf16x8*>(w + ((r >> 2) * 8 + t * 4 + (r & 3)) * 256 + s * 32 + g * 8);
-#endif
     // MFMA row i of weight tile t is output channel (i/4)*8 + t*4 + i%4 (a free permutation of the weight rows): the
     // lane that ends up with accumulator rows g*4..g*4+3 of both tiles then owns the 8 CONSECUTIVE channels g*8..g*8+7
     // of its pixel: one 16-byte store per lane, 1 KB contiguous per wave and tile.
@@ -180,7 +164,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint2*>(x + bnext + koff(s));    // tile + 2
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the compute (the scheduler sinks it otherwise)
-#if DRL_CONV1_F16
         f32x4 acc[2] = {{acc0[0][0], acc0[0][1], acc0[0][2], acc0[0][3]}, {acc0[1][0], acc0[1][1], acc0[1][2], acc0[1][3]}};
         f32x4 accb[2] = {{acc0b[0][0], acc0b[0][1], acc0b[0][2], acc0b[0][3]}, {acc0b[1][0], acc0b[1][1], acc0b[1][2], acc0b[1][3]}};
 #pragma unroll
@@ -195,15 +178,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
             }
         }
-#else
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const bf16x8 xf = u8x8_to_bf16(cur[s]);
-            acc[0] = mfma16(wf[0][s], xf, acc[0]);
-            acc[1] = mfma16(wf[1][s], xf, acc[1]);
-        }
-#endif
         const int m = tile * 16 + r;
         if (m < M) {
             constexpr float SC = 1.0f / 255.0f;          // pixel normalisation x/255 folded into the epilogue
@@ -214,7 +188,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 o[2 * t + 1] = pack_bf2(fmaxf(acc[t][2] * SC + b4[t].z, 0.f), fmaxf(acc[t][3] * SC + b4[t].w, 0.f));
             }
             *reinterpret_cast<uint4*>(out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-#if DRL_CONV1_F16
             if (pair_blk) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -223,7 +196,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
                 *reinterpret_cast<uint4*>(n3.out + (long long)m * 32 + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
             }
-#endif
         }
         bnext = f2 + p2;
     };
@@ -278,7 +250,6 @@ DRL_API int drl_conv1_fwd_dual(const void* x, const long long* frame_off1, int f
 // conv1 of TWO networks over the SAME frames (one frame-offset list): every tile is read and converted once.
 DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int frames, const void* w1, const float* bias1, void* out1,
                                const void* w2, const float* bias2, void* out2, hipStream_t s) {
-#if DRL_CONV1_F16
     if (frames <= 0 || !frame_off) return -1;
     const int M = frames * 400;
     int grid;
@@ -287,9 +258,6 @@ DRL_API int drl_conv1_fwd_pair(const void* x, const long long* frame_off, int fr
     const Conv1Net n3{frame_off, (const bf16_t*)w2, bias2, (bf16_t*)out2, M, per};
     k_conv1_direct<true, 1><<<grid, 256, 0, s>>>((const uint8_t*)x, n1, n1, n3, grid);
     return (int)hipGetLastError();
-#else
-    return -1;
-#endif
 }
 
 DRL_API int drl_conv1_set_waves(int waves_per_cu) {

@@ -40,9 +40,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 #define NTHREADS 256
-#ifndef DRL_GEMM_STORE_FIRST
-#define DRL_GEMM_STORE_FIRST 1
-#endif
+constexpr bool GEMM_STORE_FIRST = true;
 
 enum { EPI_RELU = 1, EPI_OUT_F32 = 2, EPI_ATOMIC = 4, EPI_MASK = 8, EPI_LSTM = 16, EPI_REMAP = 32 };
 
@@ -369,11 +367,9 @@ __device__ __forceinline__ bf16x8 read_frag(const uint8_t* lds, int o0, int ks, 
 // ALL of A and B through that L2 (FC1 forward, 16 x 16 tiles: 7.2 MB per XCD). Re-ordered, the tiles of one XCD are
 // consecutive ids of a grouped order (GROUP_M tile rows, column-major inside the group - 4 x 8 tiles for a 16 x 16 grid),
 // so tiles that share operand panels share an L2. Bijective for any grid (guide 5.3 "XCD swizzle must be bijective").
-#ifndef DRL_GEMM_XCD_REMAP
-#define DRL_GEMM_XCD_REMAP 1
-#endif
+constexpr bool GEMM_XCD_REMAP = true;
 __device__ __forceinline__ void tile_remap(int& bx, int& by, int gx, int gy) {
-    if (!DRL_GEMM_XCD_REMAP || gx < 2 || gy < 2) return;
+    if (!GEMM_XCD_REMAP || gx < 2 || gy < 2) return;
     constexpr int NXCD = 8, GROUP_M = 4;
     const int n = gx * gy, id = by * gx + bx;
     const int xcd = id % NXCD, q = n / NXCD, r = n % NXCD;
@@ -490,7 +486,7 @@ __device__ __forceinline__ void gemm_tile(AOp aop, BOp bop, int Mo, int No, int 
     static_assert(WM * WN == 4, "4 waves");
     static_assert(D >= 2 && D % 2 == 0, "ring depth");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;    // MFMA tiles per wave
-    constexpr bool STORE_FIRST = DRL_GEMM_STORE_FIRST;
+    constexpr bool STORE_FIRST = GEMM_STORE_FIRST;
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
     auto As = [&](int i) -> uint8_t* { return smem + i * (A_BYTES + B_BYTES); };

@@ -53,15 +53,13 @@ struct LstmXNet {
 // Arrival flags instead of a counter: atomics on one address serialise (~35 ns each, so 32 simultaneous arrivals take
 // > 1 us to land). Every workgroup owns one flag word (FLAG_STRIDE ints apart) and STORES the number of the step it has
 // finished (a write-through store, no read-modify-write); lanes 0..NWG-1 of the polling wave watch one flag each.
-#ifndef DRL_LSTM_FLAG_STRIDE
-#define DRL_LSTM_FLAG_STRIDE 32
-#endif
+constexpr int LSTM_FLAG_STRIDE = 32;
 __device__ __forceinline__ void grid_wait_fl(int* flags, int nwg, int target, int* err, int* s_dead) {
     if (threadIdx.x < 64 && !*s_dead) {
         const bool mine = (int)threadIdx.x < nwg;
         int it = 0;
         while (true) {
-            const int v = mine ? __hip_atomic_load(flags + threadIdx.x * DRL_LSTM_FLAG_STRIDE, RLX_AGENT) : target;
+            const int v = mine ? __hip_atomic_load(flags + threadIdx.x * LSTM_FLAG_STRIDE, RLX_AGENT) : target;
             if (__all((int)((unsigned)v - (unsigned)target) >= 0)) break;          // wrap-safe: flags carry a launch epoch
             if (++it > SPIN_LIMIT) { if (threadIdx.x == 0) { atomicExch(err, 1); *s_dead = 1; } break; }
             __builtin_amdgcn_s_sleep(1);
@@ -73,7 +71,7 @@ __device__ __forceinline__ void grid_wait_fl(int* flags, int nwg, int target, in
 __device__ __forceinline__ void grid_arrive_fl(int* flags, int wg, int step_done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave's h stores are acknowledged ...
     __syncthreads();                                          // ... before the one lane that raises the flag
-    if (threadIdx.x == 0) __hip_atomic_store(flags + wg * DRL_LSTM_FLAG_STRIDE, step_done, RLX_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + wg * LSTM_FLAG_STRIDE, step_done, RLX_AGENT);
 }
 
 template <int HD>
@@ -85,7 +83,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
     // (blockDim.x / 64 row blocks each, own flags) - for launches that have the chip to themselves
     const int net = blockIdx.x / (NWG * groups), grp = (blockIdx.x / NWG) % groups, wg = blockIdx.x % NWG;
     const LstmXNet a = net ? n1 : n0;
-    int* sync = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(a.hx) + HX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * DRL_LSTM_FLAG_STRIDE);
+    int* sync = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(a.hx) + HX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * LSTM_FLAG_STRIDE);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g4 = lane >> 4;
     const int wave = grp * (int)(blockDim.x >> 6) + (tid >> 6);      // row block [16 wave, 16 wave + 16) of the batch
     for (int i = tid; i < 4 * NKS * 64; i += (int)blockDim.x) {
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(256) void k_lstm_seq_fwd_x(LstmXNet n0, LstmXNet n1
     __syncthreads();
     // No memset between launches: a flag holds (launch epoch << 12) + steps finished. Every workgroup counts the launches
     // of this buffer in a word of its own (all of them run in every launch, so the counts agree without communication).
-    int* my_epoch = sync + (NWG + wg) * DRL_LSTM_FLAG_STRIDE;
+    int* my_epoch = sync + (NWG + wg) * LSTM_FLAG_STRIDE;
     const int base = (int)((unsigned)*my_epoch << 12);
     for (int t = 0; t < T; ++t) {
         float4 xq[4];
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int ste
     // a wave has to pull in after the wait; with one or two waves per workgroup that load is spread over 2-4x as many CUs.
     const int grp = blockIdx.x / NWG, wg = blockIdx.x % NWG, tid = threadIdx.x, lane = tid & 63, r = lane & 15, g4 = lane >> 4;
     const int wave = grp * (int)(blockDim.x >> 6) + (tid >> 6);      // row block [16 wave, 16 wave + 16) of the batch
-    int* sync = reinterpret_cast<int*>(a.bx + BX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * DRL_LSTM_FLAG_STRIDE);
+    int* sync = reinterpret_cast<int*>(a.bx + BX_SYNC_BYTE_OFFSET) + grp * (2 * NWG * LSTM_FLAG_STRIDE);
     // fragment (ks, lane (ii, g)) element e = W_hh[ks*32 + g*8 + e][16 wg + ii]: row n of the slice is 32 contiguous bytes
     for (int n = tid; n < 4 * HD; n += (int)blockDim.x) {
         const uint4* src = reinterpret_cast<const uint4*>(a.w_hh + (size_t)n * HD + 16 * wg);
@@ -258,7 +256,7 @@ __global__ __launch_bounds__(256) void k_lstm_bptt(BpttArgs a, int k_hi, int ste
     const unsigned ld_off = (unsigned)(((wave * NKS) * 64 + lane) * 16);
     // this lane's 16 gate columns n = 4 u0 .. 4 u0 + 15 in consumer order: k-step n/32, pieces 2 (g4 & 1) and 2 (g4 & 1) + 1
     const unsigned st_off = (unsigned)((((wave * NKS + (u0 >> 3)) * 64 + (2 * (g4 & 1)) * 16 + r) * 8) * sizeof(bf16_t));
-    int* my_epoch = sync + (NWG + wg) * DRL_LSTM_FLAG_STRIDE;
+    int* my_epoch = sync + (NWG + wg) * LSTM_FLAG_STRIDE;
     const int base = (int)((unsigned)*my_epoch << 12);
     // dh_rec of this lane's units from the dG all workgroups published for `stamp` steps
     auto recurrent = [&](int stamp) {

@@ -108,7 +108,8 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
 
 class ApexEngine(ShardedIS):
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
-                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32):
+                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
+                 halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -145,7 +146,7 @@ class ApexEngine(ShardedIS):
         # with the halo dX + a dW launch per layer, and 0.2362 ms with the dW launches on a side stream (fork / join edges
         # of the replayed graph cost more than the overlap gains). The halo dX kernels pay from ~1000 frames per launch
         # (R2D2: 2.18 -> 2.13 ms), so: by batch size.
-        self.halo_bwd = H.CONV_HALO_BWD and (B >= 1024 or os.environ.get("DRL_CONV_HALO_BWD") == "force")
+        self.halo_bwd = H.CONV_HALO_BWD and (B >= 1024 if halo_bwd is None else bool(halo_bwd))
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
         self.wgrad_splits = wgrad_splits
@@ -154,9 +155,9 @@ class ApexEngine(ShardedIS):
         self.world = dist.world_size if dist is not None else 1
         self.use_graph = use_graph
         self._init_shard(replay, dist, dev)              # self.n_is: device scalar N_global / world (engine/shard.py)
-        self.overlap_comm = os.environ.get("DRL_OVERLAP_COMM", "1") != "0"
+        self.overlap_comm = overlap_comm
         # software-pipelined sampler: the next step's PER batch is drawn inside this step's conv1 backward launch
-        self.presample = B % 4 == 0 and os.environ.get("DRL_PRESAMPLE", "1") != "0"
+        self.presample = B % 4 == 0 and presample
         if self.presample:
             replay._next_buffers()                                        # allocate now, never inside a graph capture
         self._primed = False                                              # True once a pre-drawn batch is waiting

@@ -59,7 +59,7 @@ class AsyncIngest:
         # device copy of a block's tables (everything behind its planes): the replay scatters them with one launch
         self._tail = [torch.zeros(1 << 16, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self._prio_view = [None] * depth
-        self.fast_path = hasattr(replay, "write_staged") and __import__("os").environ.get("DRL_INGEST_FAST", "1") != "0"
+        self.fast_path = hasattr(replay, "write_staged")
         self._free: Deque[int] = deque(range(depth))
         self._staged: Deque[_Staged] = deque()          # thread -> service: copied into pinned memory
         self._retired: Deque[_Staged] = deque()         # slots retired, waiting for one more step launch

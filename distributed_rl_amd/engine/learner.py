@@ -145,15 +145,15 @@ class HipLearner:
         self.step = 0
         self._last_pub = 0.0
         self.ingested = 0
-        self.max_ahead = int(os.environ.get("DRL_LEARNER_MAX_AHEAD", "3"))     # learner steps queued ahead of the GPU
+        self.max_ahead = 3                   # loop turns queued ahead of the GPU
         self.pipe = None
         self._pub = None
-        if self.device.type == "cuda" and os.environ.get("DRL_ASYNC_INGEST", "1") != "0":
+        if self.device.type == "cuda":
             from .ingest import AsyncIngest
             # staging buffers in flight: a block lives ~7 learner steps between its retire and its commit (one more step
             # launch, the host's run-ahead, the DMA), so 4 buffers capped the ingest at ~0.5 blocks per learner step - at
             # 100 K transitions/s the actors of the system bench were waiting for ring slots
-            self.pipe = AsyncIngest(exp, self.replay, self.device, depth=int(os.environ.get("DRL_INGEST_DEPTH", "48")))
+            self.pipe = AsyncIngest(exp, self.replay, self.device, depth=48)
             # shm register: also keep the two newest versions in a device double buffer that actors on THIS GPU read
             # device to device (transport.ShmParams); rank 0 publishes, so only it exports one
             if hasattr(params, "enable_device_mirror") and (dist is None or dist.rank == 0):
@@ -189,7 +189,7 @@ class HipLearner:
         """One ingest turn between two learner steps; returns the number of items that became sampleable."""
         if self.pipe is not None:
             n = self.pipe.service()
-        else:                           # synchronous fallback (DRL_ASYNC_INGEST=0, CPU tests of this class)
+        else:                           # synchronous path (CPU tests of this class)
             n = 0
             for blk in self.exp.drain(max_blocks or self.max_blocks):
                 n += self.replay.ingest_block(blk)
@@ -295,7 +295,7 @@ class HipLearner:
         t_last, n_last, i_last = time.time(), self.step, self.ingested
         inflight = deque()
         dp = self.dist is not None and self.dist.enabled
-        stop_period = int(os.environ.get("DRL_STOP_CHECK_STEPS", "200"))
+        stop_period = 200
         # K learner steps per loop turn where the engine has them as ONE graph replay (ApexEngine.run_steps): a quarter of
         # the launches, event records and ingest turns per step; everything a step needs from the one before it is on the
         # device. Only where no periodic duty (metrics, checkpoint, the agreed stop of data-parallel ranks) falls inside.

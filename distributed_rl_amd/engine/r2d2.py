@@ -54,12 +54,6 @@ class SeqNetBuffers:
         self.hx = H.lstm_hx(device)                                     # exchange buffer of the persistent recurrence
 
 
-def defer_xg_bias(n: int, Hd: int, persistent: bool) -> bool:
-    """The library GEMM has no bias epilogue; instead of a second pass over xg (n x 4H fp32) the exchange-form recurrence
-    adds b_ih + b_hh on the fly. True when both ends agree on that (same n in seq_torso_forward and seq_recurrence)."""
-    return persistent and H.use_lib_gemm(n, 4 * Hd, 3136)
-
-
 def _save_range(save_from: Optional[int], B: int, r0: int, n: int) -> Tuple[int, int]:
     """Frames [lo, n) of a chunk that starts at row r0 whose act1 / act2 a backward pass reads: time steps >= save_from."""
     if save_from is None:
@@ -73,7 +67,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
                       persistent: bool = False, prep=None, w1=None, save_from: Optional[int] = 0) -> None:
     """Time-batched part of a DuelingLSTMDQN forward: 3 conv launches over the frames of time steps ``steps`` (default:
     all T) + ONE input-projection GEMM for those steps (throughput-bound). ``persistent``: the recurrence that follows is
-    the persistent kernel (it may take over the bias add, see defer_xg_bias)."""
+    the persistent kernel."""
     t0, t1 = steps if steps is not None else (0, T)
     r0, r1, n = t0 * B, t1 * B, (t1 - t0) * B
     x = frames if frame_off is not None else frames[r0:r1]
@@ -93,11 +87,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
     if t0 == 0:
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
     xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
-    if H.use_lib_gemm(n, 4 * Hd, 3136):        # A/B switch DRL_LIB_GEMM=1: hipBLASLt (ops.hip.lib_gemm), bias as a second pass
-        H.lib_gemm(H.NT, a3, wb.view("lstm.w_ih"), xg)
-        if not defer_xg_bias(n, Hd, persistent):
-            xg.add_(bsum)
-    elif H.use_big_gemm(n, 4 * Hd, 3136):      # 8-wave large-tile kernel (gemm_big.hip), bias in the epilogue
+    if H.use_big_gemm(n, 4 * Hd, 3136):        # 8-wave large-tile kernel (gemm_big.hip), bias in the epilogue
         H.gemm_big(H.NT, a3, wb.view("lstm.w_ih"), xg, bias=bsum)
     else:
         H.gemm(H.NT, a3, wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
@@ -118,12 +108,9 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
         H.torso_fwd(frames, torso_net(cache, fo, n, wb1, wf1, b1.act1[r0:r1], b1.act2[r0:r1], b1.act3[r0:r1],
                                       save=_save_range(save_from, B, r0, n)),
                     torso_net(cache, fo, n, wb2, wf2, None, None, b2.act3[r0:r1]), prep=prep if t0 == 0 else None)
-    elif os.environ.get("DRL_CONV1_PAIR", "1") != "0":   # every frame read and converted once, two weight sets per tile
+    else:                                                # per-layer launches: every frame read and converted once for both nets
         H.conv1_fwd_pair(frames, fo, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], wb2.view("conv1.w"),
                          wf2.view("conv1.b"), b2.act1[r0:r1])
-    else:
-        H.conv_fwd_dual(1, frames, n, wb1.view("conv1.w"), wf1.view("conv1.b"), b1.act1[r0:r1], None, n, wb2.view("conv1.w"),
-                        wf2.view("conv1.b"), b2.act1[r0:r1], frame_off1=fo, frame_off2=fo)
     for l, src, dst in ((2, "act1", "act2"), (3, "act2", "act3")) if not H.TORSO_FUSED else ():
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
                         getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1],
@@ -131,7 +118,7 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
     if t0 == 0:
         for wb, wf, buf, bsum in (net1, net2):
             H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
-    if not H.use_lib_gemm(n, 4 * Hd, 3136) and H.use_big_gemm(n, 4 * Hd, 3136):
+    if H.use_big_gemm(n, 4 * Hd, 3136):
         # the input projections of BOTH networks as one launch: a forward chunk of one network alone leaves the 256 CUs
         # half empty (72 x 64 rows = 144 tiles of 256 x 256), two of them fill the chip
         H.gemm_big(H.NT, b1.act3[r0:r1], wb1.view("lstm.w_ih"), b1.xg.view(T * B, 4 * Hd)[r0:r1], bias=bs1,
@@ -140,12 +127,7 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
         return
     for wb, wf, buf, bsum in (net1, net2):
         xg = buf.xg.view(T * B, 4 * Hd)[r0:r1]
-        if H.use_lib_gemm(n, 4 * Hd, 3136):
-            H.lib_gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg)
-            if not defer_xg_bias(n, Hd, persistent):
-                xg.add_(bsum)
-        else:
-            H.gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
+        H.gemm(H.NT, buf.act3[r0:r1], wb.view("lstm.w_ih"), xg, n, 4 * Hd, 3136, bias=bsum, flags=H.EPI_OUT_F32, big=n >= 1024)
 
 
 def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, persistent: bool,
@@ -156,10 +138,7 @@ def seq_recurrence(T: int, B: int, Hd: int, wb: ParamPack, buf: SeqNetBuffers, p
     w_hh = wb.view("lstm.w_hh")
     if persistent:
         gates = buf.gates[t0:t1] if buf.gates is not None else None
-        bias = bsum if defer_xg_bias((t1 - t0) * B, Hd, persistent) else None
-        assert bias is not None or not defer_xg_bias((t1 - t0) * B, Hd, persistent), "seq_recurrence needs bsum"
-        H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx, bias)], t1 - t0, B, Hd,
-                         buf.err)
+        H.lstm_seq_fwd_x([(buf.xg[t0:t1], w_hh, buf.hs[t0:t1 + 1], buf.cs[t0:t1 + 1], gates, buf.hx)], t1 - t0, B, Hd, buf.err)
     else:
         for t in range(t0, t1):
             H.lstm_step(buf.hs[t], w_hh, buf.xg[t], buf.cs[t], buf.hs[t + 1], buf.cs[t + 1],
@@ -176,7 +155,7 @@ def seq_heads(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNet
 
 def seq_recurrent_forward(T: int, B: int, Hd: int, wb: ParamPack, wf: ParamPack, buf: SeqNetBuffers,
                           persistent: bool, bsum: Optional[torch.Tensor] = None) -> None:
-    """Recurrence over all T steps + heads (``bsum``: see defer_xg_bias; pass what seq_torso_forward was given)."""
+    """Recurrence over all T steps + heads (``bsum``: kept for call-site symmetry with seq_torso_forward)."""
     seq_recurrence(T, B, Hd, wb, buf, persistent, bsum=bsum)
     seq_heads(T, B, Hd, wb, wf, buf)
 
@@ -193,7 +172,12 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
 class R2D2Engine(ShardedIS):
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks: int = 2):
+                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks=2, bwd_cuts=None,
+                 bptt_groups: int = 2, fwd_groups_last: int = 2):
+        """Tuning arguments (measured defaults; scripts/r2d2_bench.py --engine-arg sweeps them): ``fwd_chunks`` = number of
+        equal time chunks of the pipelined forward or explicit cut points "a,b,.."; ``bwd_chunks`` / ``bwd_cuts`` (chunk starts
+        in window steps, e.g. "48,64") of the backward; row groups of the persistent BPTT and of the last forward chunk's
+        recurrence (1, 2, 4)."""
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = dev = torch.device(device)
         self.A, self.B, self.T, self.Hd = n_action, cfg.batch_size, cfg.total_len, cfg.hidden
@@ -248,28 +232,26 @@ class R2D2Engine(ShardedIS):
         contiguous = s1.offset == s0.offset + s0.numel and s0.offset % 4 == 0 and (s0.numel + s1.numel) % 4 == 0
         self.keep = (s0.offset, s1.offset + s1.numel) if contiguous else (0, 0)
         _os = os
-        self.busy_aware = _os.environ.get("DRL_HALO_BUSY", "1") != "0"   # size persistent conv grids around the recurrences
+        self.busy_aware = True                            # size persistent conv grids around the recurrences
         # row groups of the persistent BPTT (32 workgroups each; lstm_seq.hip): 80 steps alone take 366 / 270 / 271 us
         # with 1 / 2 / 4 groups
         # the big products that run next to a recurrence count their tile rounds over the CUs it leaves free: 64 CUs hold
         # a 64 KB workgroup each, no gemm_big tile (96-144 KB of LDS) fits beside one - 240 tiles of 256 x 256 take two
         # rounds on 192 CUs (93 -> 171 us), 128 x 128 tiles spread better (profiles/r2d2_busy_tile_sweep_r2.txt)
-        self.big_busy_aware = _os.environ.get("DRL_BIG_BUSY_AWARE", "1") != "0"
+        self.big_busy_aware = True
         # the recurrence of the LAST forward chunk has the chip to itself: row groups (lstm_seq.hip) spread its h loads
-        self.fwd_groups_last = max(1, min(4, int(_os.environ.get("DRL_FWD_GROUPS_LAST", "2"))))
+        self.fwd_groups_last = max(1, min(4, int(fwd_groups_last)))
         while self.fwd_groups_last > 1 and (self.B // 16) % self.fwd_groups_last:
             self.fwd_groups_last //= 2
-        self.bptt_groups = max(1, min(4, int(_os.environ.get("DRL_BPTT_GROUPS", "2"))))
+        self.bptt_groups = max(1, min(4, int(bptt_groups)))
         while self.bptt_groups > 1 and (self.B // 16) % self.bptt_groups:
             self.bptt_groups //= 2
-        self.big_tn = H.BIG_GEMM and NB >= 1024 and _os.environ.get("DRL_BIG_TN", "1") != "0"
-        self.bwd_chunks = max(1, int(_os.environ.get("DRL_BWD_CHUNKS", bwd_chunks)))
-        H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
+        self.big_tn = H.BIG_GEMM and NB >= 1024
+        self.bwd_chunks = max(1, int(bwd_chunks))
+        self.bwd_cuts = bwd_cuts
         # both recurrences of a chunk in one launch: equal with the plain hand-off, 2.93 vs 2.96 ms with the exchange form
-        self.dual_lstm = _os.environ.get("DRL_DUAL_LSTM", "1") != "0"
-        self.dual_torso = _os.environ.get("DRL_DUAL_TORSO", "1") != "0"   # conv layers of both networks per launch (same frames)
-        self.dual_heads = _os.environ.get("DRL_DUAL_HEADS", "1") != "0"   # FC + head of both networks per launch (needs dual_lstm)
-        self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd) and _os.environ.get("DRL_FUSED_BPTT", "1") != "0"
+        self.dual_lstm = self.dual_torso = self.dual_heads = True    # both networks per launch wherever the kernels take two
+        self.fused_bptt = H.lstm_bwd_step_supported(self.B, self.Hd)
         # the whole backward recurrence of a time chunk as ONE persistent launch (4.5 us per step instead of ~10)
         self.persistent_bptt = H.lstm_seq_supported(self.B, self.Hd) and _os.environ.get("DRL_PERSISTENT_BPTT", "1") != "0"
         if self.persistent_bptt:
@@ -278,7 +260,7 @@ class R2D2Engine(ShardedIS):
             self.bptt_dc = torch.zeros(self.B, self.Hd, device=dev)
             self.bptt_err = torch.zeros(1, dtype=torch.int32, device=dev)
         # int = number of equal time chunks of the pipelined forward; "a,b,.." = explicit cut points (time steps)
-        fc = str(_os.environ.get("DRL_FWD_CHUNKS", fwd_chunks))
+        fc = str(fwd_chunks)
         if "," in fc:
             cuts = sorted(set(int(x) for x in fc.split(",") if x.strip() and 0 < int(x) < self.T))
         else:
@@ -293,7 +275,7 @@ class R2D2Engine(ShardedIS):
                 # the input projections of both networks run as ONE large-tile launch per chunk (gemm_big.hip): keep each
                 # chunk within one round of 256 tiles of 256 x 256 (2 networks x rows/256 x 4H/256 tiles)
                 cap_rows = 256 * 256 // (2 * max(1, 4 * self.Hd // 256))
-                if H.BIG_GEMM and not H.LIB_GEMM and cuts[0] * self.B > cap_rows >= self.B and self.T * self.B <= 2 * cap_rows:
+                if H.BIG_GEMM and cuts[0] * self.B > cap_rows >= self.B and self.T * self.B <= 2 * cap_rows:
                     cuts = [max(self.T - cap_rows // self.B, min(cuts[0], cap_rows // self.B))]
         self.fwd_bounds = list(zip([0] + cuts, cuts + [self.T]))
         self.fwd_chunks = len(self.fwd_bounds)
@@ -374,9 +356,7 @@ class R2D2Engine(ShardedIS):
                         on_net = (self.on.xg[t0:t1], self.Pb.view("lstm.w_hh"), self.on.hs[t0:t1 + 1], self.on.cs[t0:t1 + 1],
                                   self.on.gates[t0:t1])
                         tg_net = (self.tg.xg[t0:t1], self.Tb.view("lstm.w_hh"), self.tg.hs[t0:t1 + 1], self.tg.cs[t0:t1 + 1], None)
-                        dfr = defer_xg_bias((t1 - t0) * B, Hd, True)
-                        H.lstm_seq_fwd_x([on_net + (self.on.hx, self.bsum_on if dfr else None),
-                                          tg_net + (self.tg.hx, self.bsum_tg if dfr else None)], t1 - t0, B, Hd, self.on.err,
+                        H.lstm_seq_fwd_x([on_net + (self.on.hx,), tg_net + (self.tg.hx,)], t1 - t0, B, Hd, self.on.err,
                                          groups=self.fwd_groups_last if st_ is self.fwd_bounds[-1] else 1)
                 else:
                     with fj.fork(2):
@@ -442,7 +422,7 @@ class R2D2Engine(ShardedIS):
             # the persistent chain is faster than the torso backward it feeds: a smaller newest chunk starts the torso
             # earlier (2.49 / 2.44 / 2.43 / 2.45 ms for a cut at window step 64 / 56 / 48 / 40 of 80; more cuts: 2.59-2.61)
             starts = {0, (3 * L) // 5}
-        cuts_env = os.environ.get("DRL_BWD_CUTS")                 # explicit chunk starts in window steps, e.g. "48,64"
+        cuts_env = self.bwd_cuts                                  # explicit chunk starts in window steps, e.g. "48,64"
         if cuts_env:
             starts = {0} | {int(c) for c in cuts_env.split(",") if c.strip() and 0 < int(c) < L}
         order = sorted(starts)
@@ -485,9 +465,7 @@ class R2D2Engine(ShardedIS):
                 H.gemm(H.TN, dG, on.hs[burn:T].view(NB, Hd), G.view("lstm.w_hh"), 4 * Hd, Hd, NB, flags=H.EPI_OUT_F32, big=False)
             H.colsum(dG, G.view("lstm.b_ih"), NB, 4 * Hd)
             G.view("lstm.b_hh").copy_(G.view("lstm.b_ih"))
-        if H.use_lib_gemm(4 * Hd, 3136, NB):
-            H.lib_gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"))
-        elif H.use_big_gemm(4 * Hd, 3136, NB):
+        if H.use_big_gemm(4 * Hd, 3136, NB):
             H.gemm_big(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"))
         else:
             H.gemm(H.TN, dG, on.act3[r0:], G.view("lstm.w_ih"), 4 * Hd, 3136, NB, flags=H.EPI_OUT_F32, big=False)
@@ -507,10 +485,7 @@ class R2D2Engine(ShardedIS):
         a3, a2, a1 = on.act3[r0 + lo:r0 + hi], on.act2[r0 + lo:r0 + hi], on.act1[r0 + lo:r0 + hi]
         d3, d2, d1 = self.d3[lo * 49:hi * 49], self.d2[lo * 81:hi * 81], self.d1[lo * 400:hi * 400]
         sp = max(8, self.wgrad_splits * n // NB)
-        if H.use_lib_gemm(n, 3136, 4 * Hd):
-            H.lib_gemm(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136))
-            H.relu_mask(d3, a3, d3)                                 # the mask the fused epilogue would have applied
-        elif H.use_big_gemm(n, 3136, 4 * Hd):
+        if H.use_big_gemm(n, 3136, 4 * Hd):
             busy_g = 32 * self.bptt_groups if (k0 > 0 and self.persistent_bptt and self.big_busy_aware) else 0
             H.gemm_big(H.NN, dG, Pb.view("lstm.w_ih"), d3.view(n, 3136), mask=a3, cus=256 - busy_g)   # ReLU mask in the epilogue
         else:

@@ -36,7 +36,6 @@ class R2D2ActorEngine:
         self.A, self.E, self.cfg = n_action, num_envs, cfg
         self.Hd = Hd = cfg.hidden
         self.device = dev = torch.device(device)
-        H.use_lib_gemm(1 << 20, 1 << 10, 1 << 10)        # probe the library-GEMM path now: never inside a graph capture
         self.done_offset = done_offset
         model = init_model if init_model is not None else DuelingLSTMDQN(n_action, num_envs, cfg.burn_in, cfg.nstep)
         self.P = ParamPack(r2d2_layout(n_action, hidden=Hd), dev)

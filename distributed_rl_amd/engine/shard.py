@@ -5,7 +5,7 @@ Rank r draws its batch from its own shard, so item i is drawn with probability `
 contributes 1/W of the global batch) and its importance weight is ``(N_global * p_i / (W * Σp_r))^-β``. The kernels compute
 ``(n * p_i / Σp_local)^-β`` with ``n`` read from an int64 DEVICE scalar at sampling time, so all a sharded run has to do is
 keep ``n = N_global / W`` in that scalar: ``ShardedIS.n_is``. It is refreshed OUTSIDE the captured step graph every
-``DRL_SHARD_REFRESH`` steps (one 8-byte all-reduce, no host synchronisation), so shards that fill at different rates
+``shard_refresh`` (64) steps (one 8-byte all-reduce, no host synchronisation), so shards that fill at different rates
 stay correct without re-capturing anything; with one rank it simply aliases the replay's own item counter.
 
 The max-weight normalisation of the batch stays per rank (its own batch's maximum): the global maximum would need a
@@ -14,15 +14,13 @@ deviation, README).
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 
 class ShardedIS:
     def _init_shard(self, replay, dist, device) -> None:
         self._shard_on = dist is not None and dist.enabled and dist.world_size > 1
-        self.shard_refresh = max(1, int(os.environ.get("DRL_SHARD_REFRESH", "64")))
+        self.shard_refresh = 64
         if self._shard_on:
             self.n_is = torch.zeros(1, dtype=torch.int64, device=device)
             self._n_tmp = torch.zeros(1, dtype=torch.int64, device=device)

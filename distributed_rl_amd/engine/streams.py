@@ -4,7 +4,7 @@ Most kernels of a learner step are too small to fill 256 CUs (a 64x64-tile GEMM 
 step with 32), and the step has plenty of independent work: the target-network forward next to the online forward,
 every weight-gradient GEMM next to the input-gradient chain of its layer. ``ForkJoin`` issues such branches on side
 streams; under ``torch.cuda.graph`` capture the ``wait_stream`` edges become parallel branches of the hipGraph, in eager
-mode they are ordinary event waits. ``DRL_OVERLAP=0`` disables it (everything on the current stream).
+mode they are ordinary event waits. ``enabled=False`` runs everything on the current stream.
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ import torch
 
 class ForkJoin:
     def __init__(self, device, n_side: int = 2, enabled: bool = True):
-        self.enabled = enabled and os.environ.get("DRL_OVERLAP", "1") != "0"
+        self.enabled = enabled
         self.side = [torch.cuda.Stream(device) for _ in range(n_side)] if self.enabled else []
         self._open = set()           # side streams forked since the last join
 

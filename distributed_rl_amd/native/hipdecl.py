@@ -81,7 +81,6 @@ SIGS = {
     "drl_add2": [P, P, P, I, P],
     # conv_bwd.hip
     "drl_colsum": [P, I, I, P, P],
-    "drl_relu_mask": [P, P, P, L, P],
     # xgmi_ar.hip
     "drl_xar_create": [I, I, L, I, c_double, POINTER(c_void_p)],
     "drl_xar_create2": [I, I, L, I, c_double, I, POINTER(c_void_p)],

@@ -293,7 +293,7 @@ def gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, M: int, N
 # ---- large-tile GEMM (csrc/hip/gemm_big.hip): the big dense products of the R2D2 step -------------------------------
 # tile ids: 0 = 256x256 (2 LDS stages) | 1 = 256x128 (3) | 2 = 128x256 (3) | 3 = 128x128 (4) | 4 = 256x128 (2) | 5 = 128x128 (3)
 BIG_TILES = {0: (256, 256), 1: (256, 128), 2: (128, 256), 3: (128, 128), 4: (256, 128), 5: (128, 128)}
-BIG_GEMM = os.environ.get("DRL_BIG_GEMM", "1") != "0"
+BIG_GEMM = True
 BIG_GEMM_MIN_FLOP = 2.0e10
 
 
@@ -355,14 +355,14 @@ CONV_FWD_TILED_VARIANT = {2: 0, 3: 1}
 
 
 # conv2 / conv3 forward through the LDS-halo kernels (conv_halo.hip: whole input frames staged in LDS once, weights in
-# registers). DRL_CONV_HALO=0 falls back to the implicit-GEMM tiles of gemm.hip (A/B switch).
-CONV_HALO = os.environ.get("DRL_CONV_HALO", "1") != "0"
+# registers); the implicit-GEMM tiles of gemm.hip remain for the no-ReLU / explicitly tiled calls (tests, kbench)
+CONV_HALO = True
 # ... and their input gradients (zero-padded dy through the same kernel, pre-transformed weights written by extra
 # workgroups of the conv2 forward launch); the weight / bias gradients stay in the k_multi launch without its dgrad body
-CONV_HALO_BWD = CONV_HALO and os.environ.get("DRL_CONV_HALO_BWD", "1") != "0"
+CONV_HALO_BWD = True
 # variant 0 = two workgroups per CU, 1 = one per CU. Measured (scripts/conv_halo_bench.py, us, v0 / v1 / implicit GEMM):
 #   conv2 1024+512 frames 19.2 / 17.9 / 24.5, 2 x 3840 frames 48.7 / 54.6 / 95.0;  conv3 15.5 (v1) / 20.3, 34.2 (v1) / 62.8
-CONV_HALO_VARIANT = {2: int(os.environ.get("DRL_CONV2_HALO_VARIANT", "-1")), 3: int(os.environ.get("DRL_CONV3_HALO_VARIANT", "1"))}
+CONV_HALO_VARIANT = {2: -1, 3: 1}           # -1: by frame count (conv_halo_fwd)
 
 
 import contextlib
@@ -500,8 +500,8 @@ def conv_halo_dgrad(layer: int, dy: torch.Tensor, wt: torch.Tensor, act_in: torc
     _ck(native.hip().drl_conv_halo_dgrad(layer, _p(dy), frames, _p(wt), _p(act_in), _p(dx), _s()), "conv_halo_dgrad")
 
 
-# conv2 / conv3 weight gradients through the LDS-halo kernel where the input gradients use theirs (A/B switch)
-CONV_HALO_WGRAD = CONV_HALO_BWD and os.environ.get("DRL_CONV_HALO_WGRAD", "1") != "0"
+# conv2 / conv3 weight gradients through the LDS-halo kernel where the input gradients use theirs
+CONV_HALO_WGRAD = True
 
 
 def conv_wgrad_ws(layer: int, device) -> torch.Tensor:
@@ -558,12 +558,6 @@ def conv_fwd(layer: int, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, o
         tiled = CONV_FWD_TILED_VARIANT.get(layer, 0)
     _ck(native.hip().drl_conv_fwd(layer, _p(x), _p(frame_off), frames, _p(w), _p(bias), _p(out),
                                   (1 if relu else 0) | (tiled << 8), _s()), "conv_fwd")
-
-
-if os.environ.get("DRL_CONV1_WAVES"):                 # tuning hook: wave slots per CU the conv1 tiles are dealt to (default 8)
-    native.hip().drl_conv1_set_waves(int(os.environ["DRL_CONV1_WAVES"]))
-if os.environ.get("DRL_BPTT_GROUPS"):                 # tuning hook: row groups of the persistent BPTT (1, 2, 4; default 4)
-    native.hip().drl_lstm_set_bptt_groups(int(os.environ["DRL_BPTT_GROUPS"]))
 
 
 def conv_fwd_dual(layer: int, x1, f1: int, w1, b1, out1, x2, f2: int, w2, b2, out2, frame_off1=None, frame_off2=None,
@@ -754,53 +748,6 @@ def colsum(dy: torch.Tensor, db: torch.Tensor, M: int, N: int) -> None:
     _ck(native.hip().drl_colsum(_p(dy), M, N, _p(db), _s()), "colsum")
 
 
-# ---- library GEMM for the big PLAIN products ---------------------------------------------------------------------------
-# The hand-written tiled kernel (gemm.hip) is built for the small, latency-bound GEMMs of the Ape-X step and for fused
-# epilogues / implicit operands. On the few LARGE plain products of the R2D2 step (no epilogue, both operands dense) the
-# vendor library is 2-3x faster (measured, scripts/debug/mm_bench.py: 7680x2048x3136 NT 93 us vs 232 us, 2048x3136x5120
-# TN 102 vs 195 us, 5120x3136x2048 NN 95 vs 177 us), so those - and only those - go to hipBLASLt through torch.mm with fp32
-# accumulation and (where the consumer wants it) fp32 output. DRL_LIB_GEMM=0 keeps everything on gemm.hip.
-LIB_GEMM = os.environ.get("DRL_LIB_GEMM", "0") != "0"       # hipBLASLt for the big plain products: off (gemm_big.hip), A/B switch only
-LIB_GEMM_MIN_FLOP = float(os.environ.get("DRL_LIB_GEMM_MIN_FLOP", "2.0e10"))
-
-
-_LIB_GEMM_PROBED = None
-
-
-def _lib_gemm_available() -> bool:
-    """torch.mm(bf16, bf16, out_dtype=float32, out=...) exists in this PyTorch build and runs on this device? Probed once;
-    a build without it simply keeps every GEMM on gemm.hip."""
-    global _LIB_GEMM_PROBED
-    if _LIB_GEMM_PROBED is None:
-        try:
-            a = torch.ones(16, 16, dtype=torch.bfloat16, device="cuda")
-            o = torch.empty(16, 16, dtype=torch.float32, device="cuda")
-            torch.mm(a, a, out_dtype=torch.float32, out=o)
-            _LIB_GEMM_PROBED = bool(abs(float(o[0, 0]) - 16.0) < 1e-3)
-        except Exception:
-            _LIB_GEMM_PROBED = False
-    return _LIB_GEMM_PROBED
-
-
-def use_lib_gemm(M: int, N: int, K: int) -> bool:
-    return LIB_GEMM and 2.0 * M * N * K >= LIB_GEMM_MIN_FLOP and _lib_gemm_available()
-
-
-def lib_gemm(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> None:
-    """c = a·bᵀ (NT), a·b (NN) or aᵀ·b (TN) for 2-D bf16 a, b; c bf16 or fp32 (fp32 accumulation either way)."""
-    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
-    lhs = a.t() if mode == TN else a
-    rhs = b.t() if mode == NT else b
-    if c.dtype == torch.float32:
-        torch.mm(lhs, rhs, out_dtype=torch.float32, out=c)
-    else:
-        torch.mm(lhs, rhs, out=c)
-
-
-def relu_mask(a: torch.Tensor, mask: torch.Tensor, out: torch.Tensor) -> None:
-    _ck(native.hip().drl_relu_mask(_p(a), _p(mask), _p(out), a.numel(), _s()), "relu_mask")
-
-
 # ---- LSTM ----------------------------------------------------------------------------------------------
 def lstm_step(h_prev, w_hh, xg_t, c_prev, h_out, c_out, gates_out=None) -> None:
     """One recurrent step on gate-interleaved weights: (h,c) <- cell(xg_t + h_prev·W_hhᵀ, c_prev)."""
@@ -855,7 +802,7 @@ def lstm_bptt(dhs, gates, cs, dG, w_hh, dh_rec, dc, bx, err, k_hi: int, steps: i
     dhs [L,M,H] bf16 (dL/dh from the heads), gates [L,M,4H] bf16, cs [L+1,M,H] f32 (cs[k] = c before step k), dG [L,M,4H]
     bf16 out, w_hh [4H,H] bf16; dh_rec / dc [M,H] f32 carry the chain between launches (``first``: start from zero,
     ``carry``: write them for the launch that continues). ``groups``: independent row groups of 32 workgroups each
-    (1, 2 or 4, dividing M/16; 0 = the library default, ``DRL_BPTT_GROUPS``)."""
+    (1, 2 or 4, dividing M/16; 0 = the library default)."""
     L, M, Hd = dhs.shape
     _chk(dhs, torch.bfloat16, "dhs"); _chk(gates, torch.bfloat16, "gates"); _chk(cs, torch.float32, "cs"); _chk(dG, torch.bfloat16, "dG")
     _chk(w_hh, torch.bfloat16, "w_hh"); _chk(dh_rec, torch.float32, "dh_rec"); _chk(dc, torch.float32, "dc")

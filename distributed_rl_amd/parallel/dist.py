@@ -110,7 +110,7 @@ class Dist:
         # the communication buffer lives in ordinary (cached) device memory; if THAT form does not reproduce the process
         # group's sums on this node (every other failure - no IPC, no peer access - is independent of the memory kind),
         # the same protocol is tried once more on fine-grained memory, which needs no cache maintenance to be coherent
-        kinds = [k for k in os.environ.get("DRL_XGMI_MEM", "coarse,fine").split(",") if k]
+        kinds = ["coarse", "fine"]
         ar, why, ok = None, "", False
         for kind in kinds:
             ar, why, ok, verified = None, "", False, False
@@ -206,7 +206,7 @@ class Dist:
         overtook the data - shows up as a wrong sum): whole buffer, an engine-like split on two channels, alternating.
         Any mismatch, launch error or timed-out poll rejects the path. The loop contains collectives of the process group:
         every rank takes all of them, whatever happens to its own kernel launches (a local failure is only recorded)."""
-        rounds = int(os.environ.get("DRL_XGMI_VERIFY_ROUNDS", "50")) if rounds is None else rounds
+        rounds = 50 if rounds is None else rounds
         g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
         cut = (numel // 41) // 64 * 64
         ar.set_timeout(1.0)                                     # a broken path must fail fast, not look like a hang
@@ -257,7 +257,7 @@ class Dist:
         if os.environ.get("DRL_XGMI_BLOCKS"):
             cands = [ar.n_blocks]
         else:
-            cands = [int(x) for x in os.environ.get("DRL_XGMI_SWEEP", "16,32,64").split(",") if x]
+            cands = [16, 32, 64]
         out = []
         for nb in cands:
             ar.set_blocks(nb)
@@ -350,7 +350,7 @@ class Dist:
             return
         import time
         torch.cuda.synchronize(self.device)
-        time.sleep(float(os.environ.get("DRL_QUIESCE_S", "0.35")))
+        time.sleep(0.35)
 
     def _trial_graph_collective(self) -> bool:
         if not self.enabled or self.device.type != "cuda" or self.backend != "nccl":

@@ -181,7 +181,7 @@ class Actor:
             self.plane_log = None
             if os.environ.get("DRL_PLANE_BLOCKS", "1") != "0":
                 stride = cfg.seq_len - cfg.overlap
-                cap = int(os.environ.get("DRL_SEQ_LOG_PLANES", "0")) or (stride * cfg.actor_batch + cfg.total_len + 64)
+                cap = stride * cfg.actor_batch + cfg.total_len + 64
                 self.plane_log = PlaneLog(self.E, cap=cap)
             self.asm = VecSequenceAssembler(self.E, cfg.nstep, cfg.gamma, cfg.burn_in, cfg.seq_len, cfg.overlap,
                                             cfg.reference_nstep_order, flush_tail=not cfg.reference_nstep_order,

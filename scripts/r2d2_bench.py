@@ -19,11 +19,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cap", type=int, default=2000)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--engine-arg", action="append", default=[], metavar="KEY=VALUE",
+                    help="tuning argument of R2D2Engine (fwd_chunks, bwd_chunks, bwd_cuts, bptt_groups, fwd_groups_last); repeatable")
     args = ap.parse_args()
+    kw = {}
+    for item in args.engine_arg:
+        k, v = item.split("=", 1)
+        kw[k] = int(v) if v.lstrip("-").isdigit() else v
     cfg = R2D2Config()
     rep = DeviceSequenceReplay(args.cap, "cuda", cfg, seed=0)
     rep.fill_synthetic(args.cap, n_action=4, seed=0)
-    eng = R2D2Engine(4, cfg, rep, "cuda", use_graph=not args.no_graph)
+    eng = R2D2Engine(4, cfg, rep, "cuda", use_graph=not args.no_graph, **kw)
     for _ in range(args.warmup):
         eng.step()
     torch.cuda.synchronize()
