@@ -145,7 +145,30 @@ def steady(dist, fn, chunk, min_s=MIN_WINDOW_S):
     return dist.max_scalar(time.perf_counter() - t0) / n, n
 
 
+def run_system_rows(args) -> dict:
+    """Whole system, concurrently, on ONE GPU: K actor processes x E envs -> shm ring -> ingest thread -> HIP learner, both
+    algorithms (a child process per run: scripts/system_bench.py)."""
+    out = {}
+    for algo in ("ape_x", "r2d2"):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "system_bench.py"), "--algorithm", algo,
+                                "--seconds", str(args.system_seconds)], capture_output=True, text=True, timeout=240, cwd=ROOT)
+            last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["system_" + algo] = json.loads(last[-1]) if last else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001
+            out["system_" + algo] = {"error": repr(e)[:200]}
+    return out
+
+
 def run_rank(args) -> int:
+    # N = 1: the whole-system rows run FIRST, while this process has not touched the GPU yet. Run after the learner benches
+    # below (as they used to be), with this process still alive, the same children measured 2 465 updates/s / 76 K env
+    # steps/s where they reach ~4 000 / ~120 K on their own (profiles/system_rows_order_r3.txt): the rows are about the
+    # system, not about what is left of the GPU next to a process that has just run 10 s of benchmarks on it.
+    system_rows = {}
+    if (not args.no_system and not args.no_extra and not args.check_ranks and args.gpus == 1
+            and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+        system_rows = run_system_rows(args)
     wd = float(os.environ.get("DRL_BENCH_WATCHDOG", "0"))
     if wd > 0:                               # debugging aid: dump every thread's stack and exit if the run takes longer
         import faulthandler
@@ -348,18 +371,7 @@ def run_rank(args) -> int:
     rank, world = dist.rank, W
     dist.close()
 
-    if not args.no_system and not args.no_extra and rank == 0 and world == 1:
-        # whole system, concurrently: K actor processes x E envs -> shm ring -> ingest thread -> HIP learner, both
-        # algorithms (a child process per run, started after this process has released the GPU memory it held)
-        torch.cuda.empty_cache()
-        for algo in ("ape_x", "r2d2"):
-            try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "system_bench.py"), "--algorithm", algo,
-                                    "--seconds", str(args.system_seconds)], capture_output=True, text=True, timeout=240, cwd=ROOT)
-                last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                extra["system_" + algo] = json.loads(last[-1]) if last else {"error": (r.stderr or r.stdout)[-300:]}
-            except Exception as e:  # noqa: BLE001
-                extra["system_" + algo] = {"error": repr(e)[:200]}
+    extra.update(system_rows)                # (N = 1: measured before anything else, see the top of this function)
     if not args.no_system and not args.no_extra and world > 1:
         # whole system on the multi-GPU node, through the launcher (what ./run.sh starts): data-parallel learner ranks +
         # placed actors, (a) co-located on every GPU, (b) learner GPUs | actor GPUs with RCCL parameter broadcast lanes.
