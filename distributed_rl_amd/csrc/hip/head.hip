@@ -20,6 +20,37 @@ __device__ __forceinline__ void load16_bf16(const bf16_t* p, float* out) {
     for (int i = 0; i < 8; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// one wave = one row: Q_j of the row in lane j (j < A); hv = the lane's 16 elements of the hidden row
+__device__ __forceinline__ float head_q_row(const bf16_t* __restrict__ h, int row, int A, const bf16_t* __restrict__ w_adv,
+                                            const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
+                                            const float* __restrict__ b_val, float (&hv)[16]) {
+    const int lane = threadIdx.x & 63;
+    load16_bf16(h + (long long)row * (2 * HID) + lane * 16, hv);
+    const bool adv_half = lane < 32;
+    const int k0 = (lane & 31) * 16;
+    float wv[16];
+    float val = 0.f;
+    if (!adv_half) {
+        load16_bf16(w_val + k0, wv);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) val += hv[i] * wv[i];
+    }
+    val = wave_sum(val) + b_val[0];
+    float my_q = 0.f, adv_sum = 0.f;       // lane j keeps adv_j
+    for (int j = 0; j < A; ++j) {
+        float acc = 0.f;
+        if (adv_half) {
+            load16_bf16(w_adv + (long long)j * HID + k0, wv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += hv[i] * wv[i];
+        }
+        acc = wave_sum(acc) + (b_adv ? b_adv[j] : 0.f);
+        adv_sum += acc;
+        if (lane == j) my_q = acc;
+    }
+    return val + my_q - adv_sum / (float)A;
+}
+
 // one wave = one row
 __device__ __forceinline__ void head_fwd_row(const bf16_t* __restrict__ h, int row, int A, const bf16_t* __restrict__ w_adv,
                                              const float* __restrict__ b_adv /* may be null */, const bf16_t* __restrict__ w_val,
@@ -211,6 +242,105 @@ __global__ __launch_bounds__(1024) void k_apex_td_dh(const float* __restrict__ q
         atomicAdd(loss_slot(st, st->step), t / (float)B);       // slot zeroed by the sampling kernel of this step
         if (blockIdx.x == 0) st->max_w = __uint_as_float(st->wmax_bits[st->step & 1]);
     }
+}
+
+// The same with the three dueling heads in front (Q_online(s), Q_online(s'), Q_target(s') of the wave's transition): the
+// Ape-X step needs no head launch of its own (k_head_fwd_dual: 5.8 us of a 205 us step for 1536 x 5 dot products).
+// grid = ceil(B/4), block = 256. h_on rows [0,B) = s, [B,2B) = s'; h_tg rows [0,B) = s'. Q values are still written
+// (statistics, tests).
+struct HeadW { const bf16_t* w_adv; const float* b_adv; const bf16_t* w_val; const float* b_val; };
+// block = 768 threads = 4 transitions x 3 waves: wave 3 t + k computes head k of transition t (0: Q_online(s), 1:
+// Q_online(s'), 2: Q_target(s')) - the three chains of dot products + wave reductions run side by side, not one after the
+// other (one wave per transition for all three: 14.6 us; this form: see profiles/apex_step_timeline_r3.txt) - the Q rows
+// meet in LDS, then wave 3 t does the TD and the dh row of its transition.
+__global__ __launch_bounds__(768) void k_apex_head_td_dh(const bf16_t* __restrict__ h_on, const bf16_t* __restrict__ h_tg, HeadW on, HeadW tg,
+                                                        float* __restrict__ q_on, float* __restrict__ q_tg, int B, int A,
+                                                        const int* __restrict__ idx, const int* __restrict__ act,
+                                                        const float* __restrict__ rew, const float* __restrict__ done,
+                                                        const float* __restrict__ p_sampled, StepState* st, float gamma_n, float alpha,
+                                                        float prio_eps, float n_scale, float* __restrict__ dq,
+                                                        float* __restrict__ new_prio, bf16_t* __restrict__ dh) {
+    __shared__ float s_q[4][3][MAX_A];
+    __shared__ float s_loss[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = wave / 3, k = wave - 3 * t;
+    const int row = blockIdx.x * 4 + t;
+    float lw = 0.f;
+    float hv[16];
+    if (row < B) {
+        const bool tgt = k == 2;                                        // wave-uniform
+        const HeadW& hw = tgt ? tg : on;
+        const float q = head_q_row(tgt ? h_tg : h_on, k == 1 ? B + row : row, A, hw.w_adv, hw.b_adv, hw.w_val, hw.b_val, hv);
+        if (lane < A) {
+            s_q[t][k][lane] = q;
+            (tgt ? q_tg : q_on)[(long long)(k == 1 ? B + row : row) * A + lane] = q;
+        }
+    }
+    __syncthreads();
+    if (row < B && k == 0) {
+        const int slot = idx ? idx[row] : row;
+        const int a = act[slot];
+        const float r = rew[slot], d = done[slot], p = p_sampled[row];
+        const float beta = st->beta, total = st->total_prio, N = (float)st->n_items * n_scale;
+        const float wmax = __uint_as_float(st->wmax_bits[st->step & 1]);
+        const float qs = lane < A ? s_q[t][0][lane] : 0.f, qn = lane < A ? s_q[t][1][lane] : -3.0e38f, qt = lane < A ? s_q[t][2][lane] : 0.f;
+        const float mx = wave_max(qn);
+        const int best = __ffsll((long long)__ballot(lane < A && qn == mx)) - 1;          // first max, like torch.argmax
+        const float y = __shfl(qt, best, WAVE) * gamma_n * (1.0f - d) + r;
+        const float diff = __shfl(qs, a, WAVE) - y;
+        const float ad = fabsf(diff);
+        const float hub = ad < 1.0f ? 0.5f * diff * diff : ad - 0.5f;
+        const float w = (p > 0.f && total > 0.f && wmax > 0.f) ? __powf(N * p / total, -beta) / wmax : 0.f;
+        lw = hub * w;
+        const float gsel = fminf(fmaxf(diff, -1.0f), 1.0f) * w / (float)B;
+        const float g = (lane == a) ? gsel : 0.f;
+        if (lane < A) dq[(long long)row * A + lane] = g;
+        if (lane == 0) new_prio[row] = __powf(hub + prio_eps, alpha);
+        const float dval = gsel;
+        const float dadv_mine = g - dval / (float)A;
+        float wv[16], acc[16];
+        const bool adv_half = lane < 32;
+        const int k0 = (lane & 31) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float dj = __shfl(dadv_mine, j, WAVE);
+            if (adv_half) {
+                load16_bf16(on.w_adv + (long long)j * HID + k0, wv);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += dj * wv[i];
+            }
+        }
+        if (!adv_half) {
+            load16_bf16(on.w_val + k0, wv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = dval * wv[i];
+        }
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = pack_bf2(hv[2 * i] > 0.f ? acc[2 * i] : 0.f, hv[2 * i + 1] > 0.f ? acc[2 * i + 1] : 0.f);
+        uint4* dst = reinterpret_cast<uint4*>(dh + (long long)row * (2 * HID) + lane * 16);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    if (lane == 0 && k == 0) s_loss[t] = lw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_slot(st, st->step), (s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3]) / (float)B);
+        if (blockIdx.x == 0) st->max_w = __uint_as_float(st->wmax_bits[st->step & 1]);
+    }
+}
+
+DRL_API int drl_apex_head_td_dh(const void* h_on, const void* h_tg, const void* w_adv1, const float* b_adv1, const void* w_val1,
+                                const float* b_val1, const void* w_adv2, const float* b_adv2, const void* w_val2, const float* b_val2,
+                                float* q_on, float* q_tg, int B, int A, const int* idx, const int* act, const float* rew,
+                                const float* done, const float* p_sampled, void* st, float gamma_n, float alpha, float prio_eps,
+                                float n_scale, float* dq, float* new_prio, void* dh, hipStream_t s) {
+    if (B <= 0 || A <= 0 || A > MAX_A) return -1;
+    const HeadW on{(const bf16_t*)w_adv1, b_adv1, (const bf16_t*)w_val1, b_val1}, tg{(const bf16_t*)w_adv2, b_adv2, (const bf16_t*)w_val2, b_val2};
+    k_apex_head_td_dh<<<(B + 3) / 4, 768, 0, s>>>((const bf16_t*)h_on, (const bf16_t*)h_tg, on, tg, q_on, q_tg, B, A, idx, act, rew, done,
+                                                  p_sampled, (StepState*)st, gamma_n, alpha, prio_eps, n_scale, dq, new_prio, (bf16_t*)dh);
+    return (int)hipGetLastError();
 }
 
 // Weight grads: see head_bwd_body.h. grid = (4, ceil(M/DW_ROWS)); block = 256.

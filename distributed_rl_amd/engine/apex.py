@@ -81,7 +81,7 @@ def torso_forward(x_u8: torch.Tensor, frame_off: Optional[torch.Tensor], n: int,
 
 def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: ParamPack, wf1: ParamPack, b1: TorsoBuffers,
                        off2: torch.Tensor, n2: int, wb2: ParamPack, wf2: ParamPack, b2: TorsoBuffers, prep=None,
-                       save1: Optional[int] = None) -> None:
+                       save1: Optional[int] = None, heads: bool = True) -> None:
     """Forward of TWO networks (online on n1 frames, target on n2 frames), 3 launches in total: the torso, FC1 and the head
     of both networks are one launch each, so the learner's step needs no second stream (no fork / join) for the target
     network. ``save1``: how many of network 1's leading frames a backward pass will read (default: all). (Sharing the s'
@@ -102,8 +102,9 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
                             prep=prep if l == 2 else None)
     H.gemm_nt_dual(b1.act3, wb1.view("fc1.w"), wf1.view("fc1.b"), b1.h, b2.act3, wb2.view("fc1.w"), wf2.view("fc1.b"), b2.h,
                    1024, 3136, flags=H.EPI_RELU)
-    H.head_fwd_dual(b1.h, wb1.view("adv2.w"), wf1.view("adv2.b"), wb1.view("val2.w"), wf1.view("val2.b"), b1.q,
-                    b2.h, wb2.view("adv2.w"), wf2.view("adv2.b"), wb2.view("val2.w"), wf2.view("val2.b"), b2.q)
+    if heads:        # (the learner's step computes them inside its TD launch: ops.hip.apex_head_td_dh)
+        H.head_fwd_dual(b1.h, wb1.view("adv2.w"), wf1.view("adv2.b"), wb1.view("val2.w"), wf1.view("val2.b"), b1.q,
+                        b2.h, wb2.view("adv2.w"), wf2.view("adv2.b"), wb2.view("val2.w"), wf2.view("val2.b"), b2.q)
 
 
 class ApexEngine(ShardedIS):
@@ -191,12 +192,15 @@ class ApexEngine(ShardedIS):
             r.sample(self.st, begin=True, is_n_scale=1.0, n_is=self.n_is)
         prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None
         torso_forward_dual(r.frames, r.frame_off, 2 * B, self.Pb, self.P, self.on, r.frame_off[B:], B, self.Tb, self.T, self.tg,
-                           prep=prep, save1=B)
+                           prep=prep, save1=B, heads=False)
         G, Pb, on = self.G, self.Pb, self.on
         h, a3 = on.h[:B], on.act3[:B]
-        # TD + head input gradient in ONE launch, one wave per transition (the max IS weight came from the sampler)
-        H.apex_td_dh(self.on.q, self.tg.q, r.idx, r.act, r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha,
-                     cfg.prio_eps, self.dq, self.new_prio, h, Pb.view("adv2.w"), Pb.view("val2.w"), self.dh)
+        # the three dueling heads + TD + head input gradient in ONE launch, one wave per transition (the max IS weight came
+        # from the sampler)
+        T, Tb = self.T, self.Tb
+        H.apex_head_td_dh(on.h, self.tg.h, (Pb.view("adv2.w"), self.P.view("adv2.b"), Pb.view("val2.w"), self.P.view("val2.b")),
+                          (Tb.view("adv2.w"), T.view("adv2.b"), Tb.view("val2.w"), T.view("val2.b")), on.q, self.tg.q, r.idx, r.act,
+                          r.rew, r.done, r.prio, self.st, cfg.gamma_n, cfg.per_alpha, cfg.prio_eps, self.dq, self.new_prio, self.dh)
         # ONE launch: fc1 dX + fc1 dW + fc1 db + head dW/db (no fork / join: each costs 5-11 us in a replayed graph)
         H.fc_bwd(self.dh, a3, Pb.view("fc1.w"), G.view("fc1.w"), G.view("fc1.b"), self.d3, B, 1024, 3136,
                  head=(self.dq, h, G.view("adv2.w"), G.view("adv2.b"), G.view("val2.w"), G.view("val2.b")))

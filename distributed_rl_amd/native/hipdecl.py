@@ -15,6 +15,7 @@ SIGS = {
     "drl_gather_f32": [P, P, P, I, I, P],
     "drl_gather_i32": [P, P, P, I, I, P],
     # td.hip
+    "drl_apex_head_td_dh": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, P, F, F, F, F, P, P, P, P],
     "drl_apex_td_dh": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, P, P, P, P, P, P, P],
     "drl_apex_td": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, I, P, P, P, P, P],
     "drl_is_weights": [P, I, P, F, P, P],

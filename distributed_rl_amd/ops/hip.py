@@ -181,6 +181,23 @@ def apex_td_dh(q_on, q_tg, idx, act, rew, done, p_sampled, st, gamma_n, alpha, p
                                     _p(dh), _s()), "apex_td_dh")
 
 
+def apex_head_td_dh(h_on, h_tg, head_on, head_tg, q_on, q_tg, idx, act, rew, done, p_sampled, st, gamma_n, alpha, prio_eps, dq,
+                    new_prio, dh, n_scale: float = 1.0) -> None:
+    """The dueling heads of Q_online(s), Q_online(s'), Q_target(s') + ``apex_td_dh`` as ONE launch (head.hip
+    k_apex_head_td_dh), one wave per transition. h_on bf16 [2B, 1024] (rows [0,B) = s, [B,2B) = s'), h_tg bf16 [B, 1024];
+    head_* = (w_adv, b_adv | None, w_val, b_val). q_on / q_tg are written too."""
+    B, A = q_tg.shape
+    assert q_on.shape == (2 * B, A) and dq.shape == (B, A) and h_on.shape == (2 * B, 1024) and h_tg.shape[0] >= B
+    for t, n in ((q_on, "q_on"), (q_tg, "q_tg"), (rew, "rew"), (done, "done"), (dq, "dq"), (new_prio, "new_prio")):
+        _chk(t, torch.float32, n)
+    _chk(act, torch.int32, "act"); _chk(h_on, torch.bfloat16, "h_on"); _chk(h_tg, torch.bfloat16, "h_tg"); _chk(dh, torch.bfloat16, "dh")
+    (wa1, ba1, wv1, bv1), (wa2, ba2, wv2, bv2) = head_on, head_tg
+    assert wa1.shape == (A, 512) and wa2.shape == (A, 512)
+    _ck(native.hip().drl_apex_head_td_dh(_p(h_on), _p(h_tg), _p(wa1), _p(ba1), _p(wv1), _p(bv1), _p(wa2), _p(ba2), _p(wv2), _p(bv2),
+                                         _p(q_on), _p(q_tg), B, A, _p(idx), _p(act), _p(rew), _p(done), _p(p_sampled), _p(st),
+                                         gamma_n, alpha, prio_eps, n_scale, _p(dq), _p(new_prio), _p(dh), _s()), "apex_head_td_dh")
+
+
 def is_weights(p_sampled, st, w_out, n_scale: float = 1.0) -> None:
     _ck(native.hip().drl_is_weights(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(w_out), _s()), "is_weights")
 
