@@ -378,3 +378,48 @@ def test_launcher_heals_a_learner_whose_persistent_kernel_timed_out(tmp_path, ru
     assert re.search(r"learner guard fired .*persistent.*with .*DRL_PERSISTENT_LSTM=0.*\(heal 1 of 3\)", out), out[-4000:]
     assert "learner exited with 0" in out and r.returncode == 0, out[-4000:]
     assert not re.search(r"actor_1 exited", out.split("learner exited with 0")[0]), out[-4000:]
+
+
+class _RankStub:
+    """What HipLearner.save / resume read of a data-parallel group (the collectives themselves are covered by
+    tests/test_xgmi_gpu.py and the 2-rank rehearsal of bench.py)."""
+    enabled = False
+
+    def __init__(self, rank, world):
+        self.rank, self.world_size = rank, world
+
+
+def test_data_parallel_checkpoint_every_rank_restores_the_same_weights_and_its_own_replay_shard(tmp_path, run_id):
+    """Data-parallel checkpoint / resume: rank 0 alone writes the weights, moments and step state (identical on
+    every rank), every rank writes ITS replay shard (model_<t>.replay.pth / .replay.r<k>.pth); on resume every rank loads
+    rank 0's weights and its own shard."""
+    from distributed_rl_amd.engine.learner import HipLearner
+    cfg = make_config("ape_x", batch_size=32, start_memory_size=64, save_timing=10 ** 9, fit_timing=10 ** 9, target_update=4)
+    learners, shards = [], []
+    for rank in (0, 1):
+        exp, par = connect("inproc", "%s_r%d" % (run_id, rank), create=True)
+        lr = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=512, device="cuda", dist=_RankStub(rank, 2), seed=rank,
+                        save_replay=True)
+        lr.replay.fill_synthetic(200 + 100 * rank, n_action=4, seed=10 + rank)       # shards of different size and content
+        learners.append(lr)
+    learners[1].engine.P.flat.copy_(learners[0].engine.P.flat)                      # DP ranks hold identical weights
+    for _ in range(3):
+        learners[0].engine.step()
+    learners[1].engine.P.flat.copy_(learners[0].engine.P.flat)
+    for lr in learners:
+        lr.step = 7
+        shards.append(lr.replay.snapshot())
+        path = lr.save(str(tmp_path))
+    names = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "model_7*")))
+    assert names == ["model_7.aux.pth", "model_7.pth", "model_7.replay.pth", "model_7.replay.r1.pth"]      # one writer of the weights
+    for rank in (0, 1):
+        exp, par = connect("inproc", "%s_b%d" % (run_id, rank), create=True)
+        l2 = HipLearner("ape_x", 4, cfg, exp, par, None, replay_size=512, device="cuda", dist=_RankStub(rank, 2), seed=rank)
+        assert l2.resume(path) == 7
+        assert torch.equal(l2.engine.P.flat, learners[0].engine.P.flat) and torch.equal(l2.engine.SQ.flat, learners[0].engine.SQ.flat)
+        n = int(shards[rank]["K"].sum())
+        assert len(l2.replay) == n == 200 + 100 * rank
+        assert torch.equal(l2.replay.act[:n].cpu(), shards[rank]["action"]) and torch.equal(l2.replay.rew[:n].cpu(), shards[rank]["reward"])
+        l2.close()
+    for lr in learners:
+        lr.close()
