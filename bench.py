@@ -303,17 +303,22 @@ def run_rank(args) -> int:
             try:    # learner -> actor GPUs: broadcast of the flat fp32 parameters, device to device over the process group
                 import torch.distributed as td
                 pb = {}
+                if dist.backend != "nccl":
+                    # rehearsal (ranks share a GPU, gloo): gloo's CUDA path stalls on back-to-back device collectives there
+                    # (parallel/dist.py _device_collectives); the number would say nothing about xGMI anyway
+                    raise RuntimeError("skipped: process group is %s, not RCCL" % dist.backend)
                 for name, numel in (("apex_13MB", eng.P.flat.numel()), ("r2d2_32MB", r2d2_layout(args.n_action).total)):
                     buf = torch.zeros(numel, device=dev)
-                    for _ in range(3):
+                    n_warm, n_it = (3, 20) if dist.backend == "nccl" else (1, 3)    # gloo (rehearsals): ~0.5 s per broadcast
+                    for _ in range(n_warm):
                         td.broadcast(buf, src=0)
                     torch.cuda.synchronize()
                     dist.barrier()
                     t0 = time.perf_counter()
-                    for _ in range(20):
+                    for _ in range(n_it):
                         td.broadcast(buf, src=0)
                     torch.cuda.synchronize()
-                    pb[name] = round(dist.max_scalar((time.perf_counter() - t0) / 20 * 1e6), 1)
+                    pb[name] = round(dist.max_scalar((time.perf_counter() - t0) / n_it * 1e6), 1)
                     del buf
                 pb["backend"] = dist.backend
                 extra["param_broadcast_us"] = pb

@@ -167,3 +167,32 @@ DRL_API int drl_r2d2_td(const float* q_on, const float* q_tg, int T, int B, int 
                                 done_offset, gamma_n, eta, rs_eps, dq, new_prio, seq_loss_out);
     return (int)hipGetLastError();
 }
+
+// ---- global max IS weight of a data-parallel batch (reference: weights / weights.max(), ape_x/learner.py:66-68) ----
+// Every rank's sampler accumulates the maximum weight of ITS share of the batch in StepState::wmax_bits. The maxima travel
+// in a small mailbox in front of the flat gradient inside the communication buffer: rank r writes its two slots at [2 r,
+// 2 r + 1] and zeros elsewhere, the gradient all-reduce (a SUM) leaves every rank's values in place, and the maximum over the
+// ranks goes back into wmax_bits - one step before the TD kernel of the batch it belongs to reads it (the batch of step
+// t + 1 is drawn inside step t).
+__global__ void k_wmax_put(const StepState* st, float* __restrict__ mailbox, int rank, int n) {
+    const int t = threadIdx.x;
+    if (t < n) mailbox[t] = (t >> 1) == rank ? __uint_as_float(st->wmax_bits[t & 1]) : 0.f;
+}
+__global__ void k_wmax_take(StepState* st, const float* __restrict__ mailbox, int world) {
+    const int t = threadIdx.x;
+    if (t < 2) {
+        float m = 0.f;
+        for (int r = 0; r < world; ++r) m = fmaxf(m, mailbox[2 * r + t]);
+        st->wmax_bits[t] = __float_as_uint(m);
+    }
+}
+DRL_API int drl_wmax_put(const void* st, float* mailbox, int rank, int world, int mailbox_floats, hipStream_t s) {
+    if (world < 1 || rank < 0 || rank >= world || 2 * world > mailbox_floats || mailbox_floats > 64) return -1;
+    k_wmax_put<<<1, 64, 0, s>>>((const StepState*)st, mailbox, rank, mailbox_floats);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_wmax_take(void* st, const float* mailbox, int world, hipStream_t s) {
+    if (world < 1 || world > 32) return -1;
+    k_wmax_take<<<1, 64, 0, s>>>((StepState*)st, mailbox, world);
+    return (int)hipGetLastError();
+}

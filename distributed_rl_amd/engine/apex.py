@@ -108,6 +108,8 @@ def torso_forward_dual(x_u8: torch.Tensor, off1: torch.Tensor, n1: int, wb1: Par
 
 
 class ApexEngine(ShardedIS):
+    MAILBOX = 32         # floats in front of the flat gradient in the communication buffer (2 per rank, 128-byte aligned)
+
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
                  halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True):
@@ -125,7 +127,14 @@ class ApexEngine(ShardedIS):
         self.T = self.P.like()                          # target fp32 (biases) ...
         self.Tb = self.P.like(torch.bfloat16)           # ... and bf16
         # flat gradient; multi-GPU: the direct xGMI all-reduce's communication buffer when that path is usable
-        self.G = self.P.like(flat=dist.grad_buffer(lay.total) if hasattr(dist, "grad_buffer") else None)
+        # data-parallel: the flat gradient sits behind a small MAILBOX inside ONE communication buffer, so the ranks' max IS
+        # weights ride in the gradient all-reduce (global normalisation of the batch, td.hip k_wmax_put / k_wmax_take)
+        self.comm = self.mailbox = None
+        if dist is not None and getattr(dist, "enabled", False) and hasattr(dist, "grad_buffer"):
+            comm = dist.grad_buffer(lay.total + self.MAILBOX)
+            self.comm = comm if comm is not None else torch.zeros(lay.total + self.MAILBOX, device=dev)
+            self.mailbox = self.comm[:self.MAILBOX]
+        self.G = self.P.like(flat=self.comm[self.MAILBOX:] if self.comm is not None else None)
         self.SQ = self.P.like()                         # RMSprop second moment
         H.cast_bf16(self.P.flat, self.Pb.flat)
         self.sync_target()
@@ -229,9 +238,13 @@ class ApexEngine(ShardedIS):
         # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
         H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
                    splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None)
+        if self.mailbox is not None:      # this rank's max IS weight(s) -> mailbox, in front of the conv slice's all-reduce
+            H.wmax_put(self.st, self.mailbox, self.dist.rank, self.world)
 
     def _optimize(self) -> None:
         cfg = self.cfg
+        if self.mailbox is not None:      # the all-reduces are done: the batch's maximum over ALL ranks
+            H.wmax_take(self.st, self.mailbox, self.world)
         H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
         H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
                        1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
@@ -249,7 +262,7 @@ class ApexEngine(ShardedIS):
 
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
-            self.dist.all_reduce_flat(self.G.flat)
+            self.dist.all_reduce_flat(self.comm if self.comm is not None else self.G.flat)
 
     def _dist_on(self) -> bool:
         return self.dist is not None and self.dist.enabled
@@ -272,7 +285,8 @@ class ApexEngine(ShardedIS):
         head()
         w_big = self.dist.all_reduce_async(self.G.flat[cut:], channel=0)
         torso()
-        w_small = self.dist.all_reduce_async(self.G.flat[:cut], channel=1)
+        small = self.comm[:self.MAILBOX + cut] if self.comm is not None else self.G.flat[:cut]     # (+ the max-w mailbox)
+        w_small = self.dist.all_reduce_async(small, channel=1)
         w_big.wait()
         w_small.wait()
         optimize()

@@ -8,9 +8,12 @@ keep ``n = N_global / W`` in that scalar: ``ShardedIS.n_is``. It is refreshed OU
 ``shard_refresh`` (64) steps (one 8-byte all-reduce, no host synchronisation), so shards that fill at different rates
 stay correct without re-capturing anything; with one rank it simply aliases the replay's own item counter.
 
-The max-weight normalisation of the batch stays per rank (its own batch's maximum): the global maximum would need a
-collective between sampling and the TD kernel; it only scales a rank's loss by a factor close to 1 (documented
-deviation, README).
+The max-weight normalisation (``weights / weights.max()``, ape_x/learner.py:66-68) is GLOBAL in the Ape-X engine: the
+batch of step t + 1 is drawn inside step t, every rank's maximum rides in a small mailbox in front of the flat gradient
+through step t's gradient all-reduce, and the maximum over the ranks is in place one step before the TD kernel reads it
+(engine/apex.py MAILBOX, td.hip k_wmax_put / k_wmax_take; the very first step, drawn at its own start, still uses the
+rank's own maximum). The R2D2 engine normalises per rank (its IS weights and TD sit in the same step as the draw: the
+global maximum would need a collective between them; it scales a rank's loss by a factor close to 1).
 """
 from __future__ import annotations
 

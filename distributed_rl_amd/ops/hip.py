@@ -198,6 +198,17 @@ def apex_head_td_dh(h_on, h_tg, head_on, head_tg, q_on, q_tg, idx, act, rew, don
                                          gamma_n, alpha, prio_eps, n_scale, _p(dq), _p(new_prio), _p(dh), _s()), "apex_head_td_dh")
 
 
+def wmax_put(st, mailbox: torch.Tensor, rank: int, world: int) -> None:
+    """This rank's two max-IS-weight slots -> its place in the mailbox (zeros elsewhere); td.hip k_wmax_put."""
+    _chk(mailbox, torch.float32, "mailbox")
+    _ck(native.hip().drl_wmax_put(_p(st), _p(mailbox), rank, world, mailbox.numel(), _s()), "wmax_put")
+
+
+def wmax_take(st, mailbox: torch.Tensor, world: int) -> None:
+    """Maximum over the ranks' mailbox slots (after the SUM all-reduce that carried them) -> StepState::wmax_bits."""
+    _ck(native.hip().drl_wmax_take(_p(st), _p(mailbox), world, _s()), "wmax_take")
+
+
 def is_weights(p_sampled, st, w_out, n_scale: float = 1.0) -> None:
     _ck(native.hip().drl_is_weights(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(w_out), _s()), "is_weights")
 

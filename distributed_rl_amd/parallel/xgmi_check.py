@@ -55,8 +55,11 @@ def engine_check(r2d2: bool) -> int:
     torch.cuda.synchronize()
     mine = eng.P.flat.cpu()
     every = [None] * dist.world_size
-    td.all_gather_object(every, (float(mine.double().sum()), float(mine.abs().double().sum()), eng._graphs[0]))
+    # (the Ape-X engine also agrees on the batch's max IS weight: the ranks' maxima travel with the gradient all-reduce)
+    max_w = None if r2d2 else eng.stats()["max_w"]
+    td.all_gather_object(every, (float(mine.double().sum()), float(mine.abs().double().sum()), eng._graphs[0], max_w))
     ok = all(e == every[0] for e in every) and bool(torch.isfinite(mine).all()) and not torch.equal(mine, p0.cpu())
+    ok = ok and (r2d2 or (max_w is not None and max_w > 0))
     ok = ok and every[0][2] == "one" and all(l == l for l in losses)
     print(json.dumps({"rank": dist.rank, "ok": ok, "sums": every[0][:2], "graph": every[0][2], "loss": losses[-1]}), flush=True)
     dist.barrier()
