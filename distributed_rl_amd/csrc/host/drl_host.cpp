@@ -235,13 +235,18 @@ void* drl_ring_try_reserve(void* h, uint64_t* ticket_out) {
     }
 }
 
-// Producer step 2: publish the filled slot.
-void drl_ring_commit(void* h, uint64_t ticket, uint64_t nbytes, uint64_t tag) {
+// Producer step 2: publish the filled slot. Returns 1, or 0 when the consumer gave this reservation up meanwhile (a producer
+// that stalled for longer than the grace period between its two steps and could not be found alive: the slot has been
+// recycled, the block is lost and the producer simply pushes it again). The compare-exchange keeps such a late commit from
+// overwriting the sequence number of a slot that already belongs to a later lap.
+int drl_ring_commit(void* h, uint64_t ticket, uint64_t nbytes, uint64_t tag) {
     Ring* r = static_cast<Ring*>(h);
     SlotHeader* s = r->slot(ticket);
     s->nbytes = nbytes; s->tag = tag;
-    s->seq.store(ticket + 1, std::memory_order_release);
+    uint64_t expect = ticket;
+    if (!s->seq.compare_exchange_strong(expect, ticket + 1, std::memory_order_release, std::memory_order_relaxed)) return 0;
     r->hdr->pushed.fetch_add(1, std::memory_order_relaxed);
+    return 1;
 }
 
 // Convenience: reserve + memcpy + commit. Returns 1 on success, 0 if full, -1 if too large.
@@ -252,8 +257,7 @@ int drl_ring_push(void* h, const void* data, uint64_t nbytes, uint64_t tag) {
     void* p = drl_ring_try_reserve(h, &t);
     if (!p) return 0;
     memcpy(p, data, nbytes);
-    drl_ring_commit(h, t, nbytes, tag);
-    return 1;
+    return drl_ring_commit(h, t, nbytes, tag);          // 0: the reservation was given up meanwhile, push again
 }
 
 // Consumer step 1 (single consumer): peek the oldest committed slot. NULL when empty (or when the
@@ -284,10 +288,13 @@ void* drl_ring_try_acquire(void* h, uint64_t* ticket_out, uint64_t* nbytes_out, 
         const bool signed_by_claimant = ot == pos + 1;
         const bool alive = signed_by_claimant && pid != 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM);
         if (alive) { r->stall_since_ns = now; return nullptr; }      // slow, not dead: look again after another grace period
-        if (s->seq.load(std::memory_order_acquire) != pos) continue;  // it committed after all
+        // claim the skip with a compare-exchange on the sequence number: a commit that lands at this very moment wins
+        // (the loop then finds the slot readable), a commit that comes later fails cleanly (drl_ring_commit)
+        uint64_t expect = pos;
+        if (!s->seq.compare_exchange_strong(expect, pos + r->hdr->n_slots, std::memory_order_acq_rel, std::memory_order_acquire))
+            continue;
         r->hdr->abandoned.fetch_add(1, std::memory_order_relaxed);
         r->hdr->head.store(pos + 1, std::memory_order_relaxed);
-        s->seq.store(pos + r->hdr->n_slots, std::memory_order_release);
         r->stall_pos = ~0ull;
     }
 }

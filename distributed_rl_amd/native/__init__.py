@@ -57,7 +57,7 @@ def _declare_host(lib) -> None:
         "drl_ring_slot_bytes": (c_uint64, [c_void_p]),
         "drl_ring_n_slots": (c_uint64, [c_void_p]),
         "drl_ring_try_reserve": (c_void_p, [c_void_p, u64p]),
-        "drl_ring_commit": (None, [c_void_p, c_uint64, c_uint64, c_uint64]),
+        "drl_ring_commit": (c_int, [c_void_p, c_uint64, c_uint64, c_uint64]),
         "drl_ring_push": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64]),
         "drl_ring_try_acquire": (c_void_p, [c_void_p, u64p, u64p, u64p]),
         "drl_ring_release": (None, [c_void_p, c_uint64]),

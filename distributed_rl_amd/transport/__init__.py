@@ -150,8 +150,9 @@ class ShmExperience(ExperienceChannel):
             return False
         buf = (ctypes.c_ubyte * self.slot_bytes).from_address(ptr)
         used = codec.encode_into(buf, block, kind, actor_id, env_steps)
-        self._lib.drl_ring_commit(self._h, ticket.value, used, kind)
-        return True
+        # 0: the consumer gave the reservation up while we were filling it (a stall longer than its grace period): not
+        # published - the caller keeps the block and pushes it again, as after a full ring
+        return bool(self._lib.drl_ring_commit(self._h, ticket.value, used, kind))
 
     def acquire(self):
         """Zero-copy consumer access: returns ``(ticket, decoded views)`` or None. Call :meth:`release`."""

@@ -54,7 +54,7 @@ def test_ring_skips_reservation_of_dead_producer(run_id):
         assert ring.drain() == []
         time.sleep(0.3)
         assert ring.drain() == [] and ring.stats()["abandoned"] == 1
-        ring._lib.drl_ring_commit(ring._h, t.value, 0, 0)              # ... and may still commit (an empty block here)
+        assert ring._lib.drl_ring_commit(ring._h, t.value, 0, 0) == 1  # ... and may still commit (an empty block here)
         # the ring keeps working for a full lap afterwards
         for k in range(6):
             assert ring.push(_block(seed=k), codec.KIND_APEX, 1, k)
@@ -64,6 +64,17 @@ def test_ring_skips_reservation_of_dead_producer(run_id):
                     break
                 ring.release(got[0])
         assert ring.size() == 0
+        # a commit that comes AFTER the consumer gave the reservation up fails cleanly (it must not overwrite the sequence
+        # number of a slot that belongs to a later lap): reserved by a process that exits, skipped, then committed "late"
+        code2 = code.replace("os._exit(0)", "print(t.value, flush=True); os._exit(0)")
+        late = int(subprocess.run([sys.executable, "-c", code2], check=True, timeout=60, capture_output=True, text=True).stdout.split()[-1])
+        assert ring.drain() == []
+        time.sleep(0.3)
+        assert ring.drain() == [] and ring.stats()["abandoned"] == 2
+        assert ring._lib.drl_ring_commit(ring._h, late, 0, 0) == 0
+        for k in range(6):                                              # every slot is still reservable
+            assert ring.push(_block(seed=k), codec.KIND_APEX, 1, k)
+            assert len(ring.drain()) == 1
     finally:
         ring.close()
 
