@@ -239,7 +239,7 @@ class Dist:
 
     def _time_all_reduces(self, ar, numel: int, iters: int = 20) -> tuple:
         """us per all-reduce of the gradient buffer: (direct kernel at its best grid size, process group), max over
-        ranks. The direct kernel is timed with 16 / 32 / 64 workgroups (``DRL_XGMI_SWEEP``; a set ``DRL_XGMI_BLOCKS`` pins
+        ranks. The direct kernel is timed with 16 / 32 / 64 workgroups (a set ``DRL_XGMI_BLOCKS`` pins
         it) and left at the fastest - identical on every rank, because the decision is taken on all-reduced times."""
         import time
         tmp = torch.zeros(numel, device=self.device)
