@@ -51,3 +51,25 @@ DRL_API int drl_ingest_scatter(const void* tail, int n_seg, const long long* seg
     k_ingest_scatter<<<grid, 256, 0, s>>>(a);
     return (int)hipGetLastError();
 }
+
+// The device side of one staged block as ONE host call: planes pinned -> ring and tables pinned -> tail
+// by DMA, then the scatter launch (priorities included: one more plain segment, into the replay's pending-priority
+// array). A one-launch form that pulled planes and tables over PCIe from the GPU-addressable staging buffer was measured
+// and rejected: same host time in the running system, and the learner next to it fell into a slow mode in 2 runs of 3
+// (docs/DESIGN.md section 7).
+DRL_API int drl_ingest_block(void* planes_dst, const void* planes_src, long long planes_bytes, void* tail, const void* tail_src,
+                             long long tail_bytes, int n_seg, const long long* seg_src_off, void* const* seg_dst, const int* seg_words,
+                             int n_win, const long long* win_src_off, void* const* win_dst, const int* win_n, long long plane_base,
+                             hipStream_t s) {
+    if (!planes_dst || !planes_src || !tail || !tail_src || planes_bytes < 0 || tail_bytes <= 0) return -1;
+    for (int i = 0; i < n_seg && i < ING_MAX_SEG; ++i)
+        if (seg_src_off[i] < 0 || seg_src_off[i] + 4ll * seg_words[i] > tail_bytes) return -1;
+    for (int i = 0; i < n_win && i < ING_MAX_WIN; ++i)
+        if (win_src_off[i] < 0 || win_src_off[i] + 4ll * win_n[i] > tail_bytes) return -1;
+    hipError_t e = hipSuccess;
+    if (planes_bytes) e = hipMemcpyAsync(planes_dst, planes_src, (size_t)planes_bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(tail, tail_src, (size_t)tail_bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    return drl_ingest_scatter(tail, n_seg, seg_src_off, seg_dst, seg_words, n_win, win_src_off, win_dst, win_n, plane_base, s);
+}

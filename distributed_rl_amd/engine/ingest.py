@@ -37,12 +37,13 @@ from ..transport import codec
 
 
 class _Staged:
-    __slots__ = ("buf", "meta", "fields", "blk", "K", "done", "retired_at", "need")
+    __slots__ = ("buf", "meta", "fields", "fmap", "blk", "K", "done", "retired_at", "need", "fast")
 
     def __init__(self, buf, meta, fields):
         self.buf, self.meta, self.fields = buf, meta, fields
+        self.fmap = {name: (off, nb) for name, _, _, off, nb in fields}        # built on the ingest thread, not the learner's
         self.K = int(meta["K"])
-        self.blk, self.done, self.retired_at, self.need = None, None, -1, None
+        self.blk, self.done, self.retired_at, self.need, self.fast = None, None, -1, None, False
 
 
 class AsyncIngest:
@@ -58,7 +59,6 @@ class AsyncIngest:
         self._prio = [torch.zeros(max_items, device=self.device) for _ in range(depth)]
         # device copy of a block's tables (everything behind its planes): the replay scatters them with one launch
         self._tail = [torch.zeros(1 << 16, dtype=torch.uint8, device=self.device) for _ in range(depth)]
-        self._prio_view = [None] * depth
         self.fast_path = hasattr(replay, "write_staged")
         self._free: Deque[int] = deque(range(depth))
         self._staged: Deque[_Staged] = deque()          # thread -> service: copied into pinned memory
@@ -154,36 +154,45 @@ class AsyncIngest:
         self._tick += 1
         r = self.replay
         n_commit = 0
-        # 3. commit the blocks whose DMA has finished (polled: the learner stream never waits for a copy)
-        while self._copying and self._copying[0].done.query():
+        # 3. commit the blocks whose copy has finished (polled: the learner stream never waits for a copy); blocks written
+        #    by the same service call share their event, neighbours in the slot ring share the commit launch
+        fast, ev_ok = [], None
+        while self._copying and (self._copying[0].done is ev_ok or self._copying[0].done.query()):
             rec = self._copying.popleft()
-            pv = self._prio_view[rec.buf]
-            r.commit_block(rec.blk, pv if pv is not None else self._prio[rec.buf])
+            ev_ok = rec.done
+            if rec.fast:
+                fast.append(rec.blk)
+            else:
+                r.commit_block(rec.blk, self._prio[rec.buf])
             with self._lock:
                 self._free.append(rec.buf)
             n_commit += rec.K
             self.items += rec.K
             self.blocks += 1
             self.bytes += int(rec.meta["bytes"])
-        # 2. blocks retired before the previous step launch: that step has been launched, start their DMA behind it
+        if fast:
+            r.commit_blocks(fast)
+        # 2. blocks retired before the previous step launch: that step has been launched, start their copy behind it
         if self._retired and self._retired[0].retired_at < self._tick - 1:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                while self._retired and self._retired[0].retired_at < self._tick - 1:
-                    rec = self._retired.popleft()
-                    pv = r.write_staged(rec.blk, int(rec.meta["kind"]), self._bufs[rec.buf], rec.fields,
-                                        lambda nb, b=rec.buf: self._tail_for(b, nb)) if self.fast_path else None
-                    self._prio_view[rec.buf] = pv
-                    if pv is None:                                    # full-stack blocks: field by field
+            done, raw = torch.cuda.Event(), self.stream.cuda_stream
+            while self._retired and self._retired[0].retired_at < self._tick - 1:
+                rec = self._retired.popleft()
+                rec.fast = self.fast_path and r.write_staged(rec.blk, int(rec.meta["kind"]), self._bufs[rec.buf], rec.fmap,
+                                                             lambda nb, b=rec.buf: self._tail_for(b, nb), raw)
+                if not rec.fast:                                      # full-stack blocks: field by field (torch ops)
+                    with torch.cuda.stream(self.stream):
                         v = self._views(rec)
                         r.write_views(rec.blk, int(rec.meta["kind"]), v)     # plane pool / stacks / sequences: the replay knows
                         self._prio[rec.buf][:rec.K].copy_(v["prio"], non_blocking=True)
-                    rec.done = torch.cuda.Event()
-                    rec.done.record(self.stream)
-                    self._copying.append(rec)
-        # 1. newly staged blocks: reserve + retire their destination slots on the learner stream
+                rec.done = done
+                self._copying.append(rec)
+            done.record(self.stream)
+        # 1. newly staged blocks: reserve their destination ranges; what owned them leaves the tree on the learner stream
+        #    (one retire launch per run of neighbouring evicted blocks)
+        evicted = [] if hasattr(r, "retire_ranges") else None
         while True:
             with self._lock:
                 rec = self._staged.popleft() if self._staged else None
@@ -192,9 +201,11 @@ class AsyncIngest:
             if rec.K > self._prio[rec.buf].numel():
                 self._prio[rec.buf] = torch.zeros(rec.K, device=self.device)
             K, M = rec.need
-            rec.blk = r.reserve_block(K, M)           # ranges of the replay's rings; whatever owned them leaves the tree
+            rec.blk = r.reserve_block(K, M, evicted) if evicted is not None else r.reserve_block(K, M)
             rec.retired_at = self._tick
             self._retired.append(rec)
+        if evicted:
+            r.retire_ranges(evicted)
         return n_commit
 
     def pending(self) -> int:

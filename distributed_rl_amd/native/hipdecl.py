@@ -52,6 +52,7 @@ SIGS = {
     "drl_allgather_bench": [I, I, I, I, I, P, P],
     # ingest.hip
     "drl_ingest_scatter": [P, I, P, P, P, I, P, P, P, L, P],
+    "drl_ingest_block": [P, P, L, P, P, L, I, P, P, P, I, P, P, P, L, P],
     # ipc_mirror.hip
     "drl_ipc_alloc": [U, P, P],
     "drl_ipc_free": [P],

@@ -6,6 +6,7 @@ fallback here: if ``libdrl_hip.so`` is missing these raise (oracle implementatio
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import Optional, Sequence
 
@@ -457,6 +458,38 @@ def ingest_scatter(tail: torch.Tensor, segs, wins, plane_base: int) -> None:
         (CI * max(ns, 1))(*[s[2] for s in segs]), nw, (LL * max(nw, 1))(*[w[0] for w in wins]),
         (VP * max(nw, 1))(*[w[1].data_ptr() for w in wins]), (CI * max(nw, 1))(*[w[2] for w in wins]), int(plane_base), _s()),
         "ingest_scatter")
+
+
+class _IngestArgs:
+    """Reused ctypes argument arrays of ``ingest_block`` (building six arrays per block cost more than the launch)."""
+    def __init__(self):
+        LL, VP, CI = ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int
+        self.so, self.sd, self.sn = (LL * 8)(), (VP * 8)(), (CI * 8)()
+        self.wo, self.wd, self.wn = (LL * 2)(), (VP * 2)(), (CI * 2)()
+
+
+_ingest_args = threading.local()
+
+
+def ingest_block(planes_dst: int, planes_src: int, planes_bytes: int, tail: torch.Tensor, tail_src: int, tail_bytes: int,
+                 segs, wins, plane_base: int, stream: Optional[int] = None) -> None:
+    """The device side of one staged experience block as ONE host call (ingest.hip) on ``stream`` (a raw handle; None: the
+    current stream): DMA of the planes from pinned memory (``planes_src``, a host address) into the plane ring
+    (``planes_dst``), DMA of the tables (``tail_src``) into the device buffer ``tail``, one scatter launch. Addresses are
+    raw (``data_ptr()`` + byte offset: no tensor views are built per block); segs = [(byte offset in the tables, dst address
+    of 32-bit words, count)], wins = [(byte offset of an int32 plane-index table, dst address of int64, count)]: dst[i] =
+    (src[i] + plane_base) * 7056. The CALLER has checked the destination ranges against its tables."""
+    ns, nw = len(segs), len(wins)
+    assert ns <= 8 and nw <= 2 and tail.dtype == torch.uint8 and tail.is_cuda and 0 < tail_bytes <= tail.numel()
+    a = getattr(_ingest_args, "a", None)
+    if a is None:
+        a = _ingest_args.a = _IngestArgs()
+    for i, (off, dst, n) in enumerate(segs):
+        a.so[i], a.sd[i], a.sn[i] = off, dst, n
+    for i, (off, dst, n) in enumerate(wins):
+        a.wo[i], a.wd[i], a.wn[i] = off, dst, n
+    _ck(native.hip().drl_ingest_block(planes_dst, planes_src, planes_bytes, tail.data_ptr(), tail_src, tail_bytes, ns, a.so, a.sd,
+                                      a.sn, nw, a.wo, a.wd, a.wn, plane_base, _s() if stream is None else stream), "ingest_block")
 
 
 class TorsoNet:

@@ -57,6 +57,7 @@ class DevicePER(RingPair):
         self.rew = torch.zeros(self.capacity, device=dev)
         self.done = torch.zeros(self.capacity, device=dev)
         self.n_items = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.prio_pending = torch.zeros(self.capacity, device=dev)      # priorities of written, not yet committed blocks
         self._scratch = torch.zeros(max(max_ingest, 64), dtype=torch.int32, device=dev)
         self._init_rings()           # cursor / pcursor / count (host view; n_items is the device copy) / block deque
         self._warned_planes = False
@@ -97,13 +98,22 @@ class DevicePER(RingPair):
     # Three stages, so that the bulk copy can run on its own stream while the learner keeps stepping (engine/ingest.py):
     # reserve_block (ranges of both rings; everything that still owns part of them leaves the tree: nothing samples it any
     # more), write_block (the data, any stream), commit_block (priorities + generation + item count, one launch).
+    def _need_scratch(self, n: int) -> None:
+        if n > self._scratch.numel():
+            self._scratch = torch.zeros(n, dtype=torch.int32, device=self.device)
+
     def _retire(self, slot: int, K: int) -> None:
+        self._need_scratch(K)
         H.sumtree_ingest(self.tree, self.lay, slot, None, self.gen, self._scratch, n=K, n_items=self.n_items,
                          n_items_val=self.count)
 
-    def reserve_block(self, K: int, M: int) -> _Block:
-        if K > self._scratch.numel():
-            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
+    def _commit_range(self, slot: int, n: int) -> None:
+        self._need_scratch(n)
+        H.sumtree_ingest(self.tree, self.lay, slot, self.prio_pending[slot:slot + n], self.gen, self._scratch, n=n,
+                         n_items=self.n_items, n_items_val=self.count)
+
+    def reserve_block(self, K: int, M: int, deferred=None) -> _Block:
+        self._need_scratch(K)
         if M > 2 * STACK * K - 1 and not self._warned_planes and M * self.capacity > 2 * K * self.plane_capacity:
             # producers that send full stacks (codec kind 1: 8 planes per transition) into a plane ring sized for plane-pool
             # blocks (~1.3): whole blocks are evicted early and the replay holds far fewer items than its capacity says
@@ -112,7 +122,7 @@ class DevicePER(RingPair):
             warnings.warn("replay: blocks carry %.1f planes per transition but the plane ring was sized for %.1f: at most ~%d "
                           "of the %d transitions stay resident (size it with planes_per_item / DRL_PLANES_PER_ITEM)"
                           % (M / K, self.plane_capacity / self.capacity, self.plane_capacity * K // M, self.capacity))
-        return RingPair.reserve_block(self, K, M)
+        return RingPair.reserve_block(self, K, M, deferred)
 
     def write_block(self, blk: _Block, planes: torch.Tensor, win_s: torch.Tensor, win_s2: torch.Tensor, action: torch.Tensor,
                     reward: torch.Tensor, done: torch.Tensor) -> None:
@@ -161,28 +171,31 @@ class DevicePER(RingPair):
         from ..transport import codec
         return (K, M) if kind == codec.KIND_APEX_PLANES else (K, 2 * STACK * K)
 
-    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for) -> Optional[torch.Tensor]:
+    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for,
+                     stream: Optional[int] = None) -> bool:
         """The ingest pipeline's write of a plane-pool block straight out of its pinned staging buffer ``pin`` (fields =
-        codec.layout): ONE DMA puts the planes into the ring, ONE DMA brings the tables (everything behind the planes) into
-        the device buffer ``tail_for(nbytes)``, ONE launch scatters them (window offsets, actions, rewards, dones). Returns the
-        block's priorities as a device view of that buffer (for ``commit_block``), or None for a block kind it does not
-        take (the caller falls back to ``write_views``)."""
+        codec.layout, or its {name: (offset, bytes)} map) as ONE native call on ``stream``: a DMA puts the planes into the
+        ring, a DMA brings the tables (everything behind the planes) into the device buffer ``tail_for(nbytes)``, one launch
+        scatters them (window offsets, actions, rewards, dones; priorities into ``prio_pending`` at the block's slots, for
+        ``commit_blocks``). False for a block kind it does not take (the caller falls back to ``write_views``)."""
         from ..transport import codec
         if kind != codec.KIND_APEX_PLANES:
-            return None
-        f = {name: (off, nb) for name, _, _, off, nb in fields}
+            return False
+        f = fields if isinstance(fields, dict) else {name: (off, nb) for name, _, _, off, nb in fields}
         s, K, p, M = blk.slot, blk.K, blk.plane, blk.M
         p_off, p_nb = f["planes"]
-        assert p_nb == M * PLANE_BYTES
-        self.frames[p:p + M].view(-1).copy_(pin[p_off:p_off + p_nb], non_blocking=True)
         t0, t1 = f["win_s"][0], f["prio"][0] + f["prio"][1]
-        tail = tail_for(t1 - t0)
-        tail[:t1 - t0].copy_(pin[t0:t1], non_blocking=True)
-        o = lambda name: f[name][0] - t0                                            # noqa: E731
         cap = self.capacity
-        H.ingest_scatter(tail, [(o("action"), self.act[s:s + K], K), (o("reward"), self.rew[s:s + K], K), (o("done"), self.done[s:s + K], K)],
-                         [(o("win_s"), self.win[s:s + K], K), (o("win_s2"), self.win[cap + s:cap + s + K], K)], p)
-        return tail[o("prio"):o("prio") + 4 * K].view(torch.float32)
+        assert p_nb == M * PLANE_BYTES and 0 <= p and p + M <= self.plane_capacity and 0 <= s and s + K <= cap
+        assert t1 <= pin.numel() and p_off + p_nb <= pin.numel() and f["prio"][1] == 4 * K
+        o = lambda name: f[name][0] - t0                                            # noqa: E731
+        segs = [(o("action"), self.act.data_ptr() + 4 * s, K), (o("reward"), self.rew.data_ptr() + 4 * s, K),
+                (o("done"), self.done.data_ptr() + 4 * s, K), (o("prio"), self.prio_pending.data_ptr() + 4 * s, K)]
+        wins = [(o("win_s"), self.win.data_ptr() + 8 * s, K), (o("win_s2"), self.win.data_ptr() + 8 * (cap + s), K)]
+        dst = self.frames.data_ptr() + p * PLANE_BYTES
+        src = pin.data_ptr()
+        H.ingest_block(dst, src + p_off, p_nb, tail_for(t1 - t0), src + t0, t1 - t0, segs, wins, p, stream=stream)
+        return True
 
     def write_views(self, blk: _Block, kind: int, v) -> None:
         from ..transport import codec

@@ -76,6 +76,7 @@ class DeviceSequenceReplay(RingPair):
         self.h0 = torch.zeros(S, self.Hd, device=dev)
         self.c0 = torch.zeros(S, self.Hd, device=dev)
         self.n_items = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.prio_pending = torch.zeros(S, device=dev)                  # priorities of written, not yet committed blocks
         self._scratch = torch.zeros(1024, dtype=torch.int32, device=dev)
         self._init_rings()
         B = self.B
@@ -100,14 +101,23 @@ class DeviceSequenceReplay(RingPair):
         return sum(b.M for b in self._blocks if b.state == 1)
 
     # ---- ingest: reserve (+ retire what is in the way) / write / commit (engine/ingest.py drives the three stages) ------
+    def _need_scratch(self, n: int) -> None:
+        if n > self._scratch.numel():
+            self._scratch = torch.zeros(n, dtype=torch.int32, device=self.device)
+
     def _retire(self, slot: int, K: int) -> None:
+        self._need_scratch(K)
         H.sumtree_ingest(self.tree, self.lay, slot, None, self.gen, self._scratch, n=K, n_items=self.n_items,
                          n_items_val=self.count)
 
-    def reserve_block(self, K: int, M: int) -> _Block:
-        if K > self._scratch.numel():
-            self._scratch = torch.zeros(K, dtype=torch.int32, device=self.device)
-        return RingPair.reserve_block(self, K, M)
+    def _commit_range(self, slot: int, n: int) -> None:
+        self._need_scratch(n)
+        H.sumtree_ingest(self.tree, self.lay, slot, self.prio_pending[slot:slot + n], self.gen, self._scratch, n=n,
+                         n_items=self.n_items, n_items_val=self.count)
+
+    def reserve_block(self, K: int, M: int, deferred=None) -> _Block:
+        self._need_scratch(K)
+        return RingPair.reserve_block(self, K, M, deferred)
 
     def write_block(self, blk: _Block, planes: torch.Tensor, win: torch.Tensor, action, reward, done, length, h0, c0) -> None:
         """planes u8 [M, 84*84] (or [M,84,84]); win int32 [K, T]: index, relative to the block's planes, of the first of
@@ -176,27 +186,31 @@ class DeviceSequenceReplay(RingPair):
             return K, self.stack_block_planes(views["frames"], views["length"])
         return K, K * STACK * self.T
 
-    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for) -> Optional[torch.Tensor]:
+    def write_staged(self, blk: _Block, kind: int, pin: torch.Tensor, fields, tail_for,
+                     stream: Optional[int] = None) -> bool:
         """As DevicePER.write_staged, for sequence blocks with a plane pool (codec kind 4): planes by one DMA, the tables by
-        one DMA + one scatter launch; returns the priorities as a device view, None for other block kinds."""
+        one DMA + one scatter launch, issued by one native call; priorities go to ``prio_pending``. False for other kinds."""
         from ..transport import codec
         if kind != codec.KIND_R2D2_PLANES:
-            return None
-        f = {name: (off, nb) for name, _, _, off, nb in fields}
+            return False
+        f = fields if isinstance(fields, dict) else {name: (off, nb) for name, _, _, off, nb in fields}
         s, K, p, M, T = blk.slot, blk.K, blk.plane, blk.M, self.T
         p_off, p_nb = f["planes"]
-        assert p_nb == M * PLANE_BYTES and f["win"][1] == 4 * K * T
-        self.frames[p:p + M].view(-1).copy_(pin[p_off:p_off + p_nb], non_blocking=True)
         t0, t1 = f["win"][0], f["prio"][0] + f["prio"][1]
-        tail = tail_for(t1 - t0)
-        tail[:t1 - t0].copy_(pin[t0:t1], non_blocking=True)
-        o = lambda name: f[name][0] - t0                                            # noqa: E731
         Hd = self.h0.shape[1]
-        H.ingest_scatter(tail, [(o("action"), self.act[s:s + K], K * T), (o("reward"), self.rew[s:s + K], K * T),
-                                (o("done"), self.done[s:s + K], K * T), (o("length"), self.length[s:s + K], K),
-                                (o("h0"), self.h0[s:s + K], K * Hd), (o("c0"), self.c0[s:s + K], K * Hd)],
-                         [(o("win"), self.win[s:s + K], K * T)], p)
-        return tail[o("prio"):o("prio") + 4 * K].view(torch.float32)
+        assert p_nb == M * PLANE_BYTES and f["win"][1] == 4 * K * T and f["h0"][1] == 4 * K * Hd and f["prio"][1] == 4 * K
+        assert 0 <= p and p + M <= self.plane_capacity and 0 <= s and s + K <= self.capacity
+        assert t1 <= pin.numel() and p_off + p_nb <= pin.numel()
+        o = lambda name: f[name][0] - t0                                            # noqa: E731
+        segs = [(o("action"), self.act.data_ptr() + 4 * s * T, K * T), (o("reward"), self.rew.data_ptr() + 4 * s * T, K * T),
+                (o("done"), self.done.data_ptr() + 4 * s * T, K * T), (o("length"), self.length.data_ptr() + 4 * s, K),
+                (o("h0"), self.h0.data_ptr() + 4 * s * Hd, K * Hd), (o("c0"), self.c0.data_ptr() + 4 * s * Hd, K * Hd),
+                (o("prio"), self.prio_pending.data_ptr() + 4 * s, K)]
+        wins = [(o("win"), self.win.data_ptr() + 8 * s * T, K * T)]
+        dst = self.frames.data_ptr() + p * PLANE_BYTES
+        src = pin.data_ptr()
+        H.ingest_block(dst, src + p_off, p_nb, tail_for(t1 - t0), src + t0, t1 - t0, segs, wins, p, stream=stream)
+        return True
 
     def write_views(self, blk: _Block, kind: int, v) -> None:
         from ..transport import codec

@@ -31,7 +31,8 @@ def _overlap(a0: int, a1: int, b0: int, b1: int) -> bool:
 
 class RingPair:
     """Mixin. The host class provides ``capacity`` (items), ``plane_capacity``, ``_retire(slot, K)`` (kernel launch that
-    takes items out of the tree) and keeps ``count`` (live items)."""
+    takes items out of the tree), ``_commit_range(slot, n)`` (launch that puts items whose priorities wait in its
+    ``prio_pending`` into the tree) and keeps ``count`` (live items)."""
 
     def _init_rings(self) -> None:
         self.cursor = 0              # next item slot
@@ -40,7 +41,10 @@ class RingPair:
         self.evicted_items = 0       # items retired to make room (FIFO)
         self._blocks: Deque[Block] = deque()
 
-    def reserve_block(self, K: int, M: int) -> Block:
+    def reserve_block(self, K: int, M: int, deferred=None) -> Block:
+        """``deferred`` (a list): the evicted item ranges are appended to it instead of being retired one launch each; the
+        caller hands the list to ``retire_ranges`` before anything can sample again (engine/ingest.py reserves all blocks
+        of a service call, then retires once)."""
         if K > self.capacity or M > self.plane_capacity:
             raise ValueError("block larger than the replay (%d items / %d planes; capacity %d / %d)" %
                              (K, M, self.capacity, self.plane_capacity))
@@ -58,8 +62,11 @@ class RingPair:
             b = self._blocks.popleft()
             if b.state == 1:
                 self.count -= b.K
-                self._retire(b.slot, b.K)                         # FIFO eviction, whole blocks (the launch also lowers the
-                retired += b.K                                    # device copy of the item count: IS weights read it)
+                if deferred is None:
+                    self._retire(b.slot, b.K)                     # FIFO eviction, whole blocks (the launch also lowers the
+                else:                                             # device copy of the item count: IS weights read it)
+                    deferred.append((b.slot, b.K))
+                retired += b.K
             b.state = 2
         self.evicted_items += retired
         if slot != self.cursor or plane != self.pcursor:          # once per lap: the order argument, checked
@@ -68,3 +75,37 @@ class RingPair:
         blk = Block(slot, K, plane, M)
         self._blocks.append(blk)                                  # owner of its ranges from now on
         return blk
+
+    def retire_ranges(self, ranges) -> int:
+        """Retire the item ranges collected by ``reserve_block(deferred=...)``: neighbours in the ring (evictions are FIFO,
+        so they nearly always are) share one launch. Returns the number of launches."""
+        n_launch, run_s, run_n = 0, 0, 0
+        for slot, K in list(ranges) + [(-1, 0)]:
+            if run_n and slot == run_s + run_n:
+                run_n += K
+                continue
+            if run_n:
+                self._retire(run_s, run_n)
+                n_launch += 1
+            run_s, run_n = slot, K
+        return n_launch
+
+    def commit_blocks(self, blks) -> int:
+        """Commit blocks written by ``write_staged`` (their priorities wait in ``prio_pending`` at their own slots): blocks
+        that follow each other in the item ring - the usual case, they were reserved in that order - share ONE launch.
+        Blocks evicted while in flight (state 2) are dropped. Returns the number of launches."""
+        n_launch, run_s, run_n = 0, 0, 0
+        for blk in list(blks) + [None]:
+            if blk is not None and blk.state == 2:
+                continue
+            if blk is not None and run_n and blk.slot == run_s + run_n:
+                run_n += blk.K
+            else:
+                if run_n:
+                    self.count += run_n
+                    self._commit_range(run_s, run_n)
+                    n_launch += 1
+                run_s, run_n = (blk.slot, blk.K) if blk is not None else (0, 0)
+            if blk is not None:
+                blk.state = 1
+        return n_launch

@@ -162,6 +162,58 @@ def test_async_ingest_r2d2_inproc_channel(run_id):
         pipe.close()
 
 
+def test_async_ingest_sequence_plane_blocks_match_the_field_by_field_write(run_id):
+    """Kind-4 blocks (sequences over a plane pool) through the pipeline's one-call write (two DMAs + the scatter launch,
+    priorities through ``prio_pending``) against ``ingest_block`` (torch ops, field by
+    field) into a second replay: every table, the planes, the tree and the item count; enough blocks to wrap the rings,
+    several per service call so that retires and commits are coalesced."""
+    from distributed_rl_amd.engine.ingest import AsyncIngest
+    from distributed_rl_amd.replay.device_seq import DeviceSequenceReplay
+    dev = torch.device("cuda")
+    cfg = R2D2Config(burn_in=2, seq_len=4, nstep=2, batch_size=4)
+    T = cfg.total_len
+    rep = DeviceSequenceReplay(16, dev, cfg, seed=0, plane_capacity=200)
+    ref = DeviceSequenceReplay(16, dev, cfg, seed=0, plane_capacity=200)
+    ring = ShmExperience(shm_names(run_id)[0], create=True, n_slots=16, slot_bytes=2 << 20)
+    pipe = AsyncIngest(ring, rep, dev, depth=8, slot_bytes=2 << 20)
+    rng = np.random.default_rng(1)
+
+    def block(K):
+        per = T + 3
+        return dict(planes=rng.integers(0, 256, (K * per, 84, 84), dtype=np.uint8),
+                    win=(np.arange(K)[:, None] * per + np.arange(T)[None, :]).astype(np.int32),
+                    action=rng.integers(0, 4, (K, T)).astype(np.int32), reward=rng.standard_normal((K, T)).astype(np.float32),
+                    done=(rng.random((K, T)) < 0.1).astype(np.float32), length=rng.integers(3, T + 1, K).astype(np.int32),
+                    h0=rng.standard_normal((K, 512)).astype(np.float32), c0=rng.standard_normal((K, 512)).astype(np.float32),
+                    prio=(rng.random(K) + 0.5).astype(np.float32))
+    blocks = [block(k) for k in (3, 2, 4, 1, 3, 2, 5, 3, 2)]          # 25 sequences into 16 slots / 225 planes into 200
+    try:
+        for b in blocks:
+            assert ring.push(b, codec.KIND_R2D2_PLANES, 1, 0)
+            ref.ingest_block(b)
+        total, n, t0 = sum(b["length"].shape[0] for b in blocks), 0, time.time()
+        while n < total and time.time() - t0 < 30:
+            n += pipe.service()
+            time.sleep(0.002)
+        assert n == total and pipe.pending() == 0
+        torch.cuda.synchronize()
+        assert [(b.slot, b.K, b.plane, b.M, b.state) for b in rep._blocks] == [(b.slot, b.K, b.plane, b.M, b.state) for b in ref._blocks]
+        assert len(rep) == len(ref) == int(rep.n_items.item()) == int(ref.n_items.item())
+        live = torch.zeros(16, dtype=torch.bool, device=dev)
+        for b in rep._blocks:
+            if b.state == 1:
+                live[b.slot:b.slot + b.K] = True
+                assert torch.equal(rep.frames[b.plane:b.plane + b.M], ref.frames[b.plane:b.plane + b.M])
+        assert int(live.sum()) == len(rep) > 0
+        for name in ("win", "act", "rew", "done", "length", "h0", "c0"):
+            assert torch.equal(getattr(rep, name)[live], getattr(ref, name)[live]), name
+        assert torch.equal(rep.tree[:16], ref.tree[:16]) and float(rep.tree[:16][~live].abs().sum()) == 0.0
+        assert rep.total_prios() == pytest.approx(ref.total_prios(), rel=1e-6)
+    finally:
+        pipe.close()
+        ring.close()
+
+
 def test_plane_store_against_the_host_oracle_through_episode_boundaries(run_id):
     """The actor's own plane-pool blocks (SyntheticCatch with one life: a reset every ~26 steps, truncated n-step tails onto
     terminal frames) into a replay small enough to lap both rings several times: every transition that is still live reads
