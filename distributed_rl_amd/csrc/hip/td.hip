@@ -66,8 +66,34 @@ __global__ __launch_bounds__(1024) void k_apex_td(const float* __restrict__ q_on
 // ---------------------------------------------------------------------------------------------------
 // IS weights alone (R2D2 path / tests): w = (N p / total)^-beta / max.
 // ---------------------------------------------------------------------------------------------------
+// ``mailbox`` (data-parallel R2D2, engine/r2d2.py): the ranks' batch maxima, gathered by a small SUM all-reduce that ran
+// under the forward pass (k_is_wmax_put wrote this rank's slot, zeros elsewhere) - the weights are then normalised by the
+// maximum over ALL ranks' batches, as one big batch would be (reference: weights / weights.max(), r2d2/learner.py).
 __global__ __launch_bounds__(1024) void k_is_weights(const float* __restrict__ p_sampled, int B, StepState* st, float n_scale,
-                                                    float* __restrict__ w_out) {
+                                                    float* __restrict__ w_out, const float* __restrict__ mailbox, int world) {
+    __shared__ float red[32];
+    const float beta = st->beta, total = st->total_prio, N = (float)st->n_items * n_scale;
+    float wmax = 0.f;
+    if (mailbox) {
+        for (int r = 0; r < world; ++r) wmax = fmaxf(wmax, mailbox[r]);
+    } else {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            float p = p_sampled[b];
+            wmax = fmaxf(wmax, (p > 0.f && total > 0.f) ? __powf(N * p / total, -beta) : 0.f);
+        }
+        wmax = block_max(wmax, red);
+    }
+    const float inv = wmax > 0.f ? 1.0f / wmax : 1.0f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float p = p_sampled[b];
+        w_out[b] = (p > 0.f && total > 0.f) ? __powf(N * p / total, -beta) * inv : 0.f;
+    }
+    if (threadIdx.x == 0) { st->max_w = wmax; *loss_slot(st, st->step) = 0.f; }
+}
+
+// This rank's batch maximum -> mailbox[rank], zeros in the other n - 1 slots (the SUM all-reduce then gathers the ranks' values).
+__global__ __launch_bounds__(1024) void k_is_wmax_put(const float* __restrict__ p_sampled, int B, const StepState* st, float n_scale,
+                                                     float* __restrict__ mailbox, int rank, int n) {
     __shared__ float red[32];
     const float beta = st->beta, total = st->total_prio, N = (float)st->n_items * n_scale;
     float wmax = 0.f;
@@ -76,12 +102,7 @@ __global__ __launch_bounds__(1024) void k_is_weights(const float* __restrict__ p
         wmax = fmaxf(wmax, (p > 0.f && total > 0.f) ? __powf(N * p / total, -beta) : 0.f);
     }
     wmax = block_max(wmax, red);
-    const float inv = wmax > 0.f ? 1.0f / wmax : 1.0f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        float p = p_sampled[b];
-        w_out[b] = (p > 0.f && total > 0.f) ? __powf(N * p / total, -beta) * inv : 0.f;
-    }
-    if (threadIdx.x == 0) { st->max_w = wmax; *loss_slot(st, st->step) = 0.f; }
+    if ((int)threadIdx.x < n) mailbox[threadIdx.x] = (int)threadIdx.x == rank ? wmax : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -152,9 +173,16 @@ DRL_API int drl_apex_td(const float* q_on, const float* q_tg, int B, int A, cons
     return (int)hipGetLastError();
 }
 
-DRL_API int drl_is_weights(const float* p_sampled, int B, void* st, float n_scale, float* w_out, hipStream_t s) {
-    if (B <= 0) return -1;
-    k_is_weights<<<1, 1024, 0, s>>>(p_sampled, B, (StepState*)st, n_scale, w_out);
+DRL_API int drl_is_weights(const float* p_sampled, int B, void* st, float n_scale, float* w_out, const float* mailbox, int world,
+                           hipStream_t s) {
+    if (B <= 0 || (mailbox && (world < 1 || world > 32))) return -1;
+    k_is_weights<<<1, 1024, 0, s>>>(p_sampled, B, (StepState*)st, n_scale, w_out, mailbox, world);
+    return (int)hipGetLastError();
+}
+DRL_API int drl_is_wmax_put(const float* p_sampled, int B, const void* st, float n_scale, float* mailbox, int rank, int world,
+                            int mailbox_floats, hipStream_t s) {
+    if (B <= 0 || !mailbox || world < 1 || rank < 0 || rank >= world || world > mailbox_floats || mailbox_floats > 1024) return -1;
+    k_is_wmax_put<<<1, 1024, 0, s>>>(p_sampled, B, (const StepState*)st, n_scale, mailbox, rank, mailbox_floats);
     return (int)hipGetLastError();
 }
 

@@ -170,6 +170,8 @@ def seq_net_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T: 
 
 
 class R2D2Engine(ShardedIS):
+    MAILBOX = 32         # floats in front of the flat gradient in the communication buffer (one per rank, 128-byte aligned)
+
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
                  done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks=2, bwd_cuts=None,
@@ -192,7 +194,15 @@ class R2D2Engine(ShardedIS):
         self.Pb = self.P.like(torch.bfloat16)
         self.Tg = self.P.like()
         self.Tb = self.P.like(torch.bfloat16)
-        self.G = self.P.like(flat=dist.grad_buffer(lay.total) if hasattr(dist, "grad_buffer") else None)
+        # data-parallel: the flat gradient sits behind a small MAILBOX inside ONE communication buffer; a 128-byte all-reduce
+        # of the mailbox under the forward pass gathers the ranks' batch maxima (global IS-weight normalisation, td.hip
+        # k_is_wmax_put / k_is_weights)
+        self.comm = self.mailbox = self._gw = None
+        if dist is not None and getattr(dist, "enabled", False) and hasattr(dist, "grad_buffer"):
+            comm = dist.grad_buffer(lay.total + self.MAILBOX)
+            self.comm = comm if comm is not None else torch.zeros(lay.total + self.MAILBOX, device=dev)
+            self.mailbox = self.comm[:self.MAILBOX]
+        self.G = self.P.like(flat=self.comm[self.MAILBOX:] if self.comm is not None else None)
         self.M1 = self.P.like()
         self.M2 = self.P.like()
         H.cast_bf16(self.P.flat, self.Pb.flat)
@@ -310,6 +320,10 @@ class R2D2Engine(ShardedIS):
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
         r.sample(self.st, begin=True, n_is=self.n_is)               # step_begin fused; G was zeroed by the optimizer
+        wmax_work = None
+        if self._global_wmax():             # this rank's batch maximum -> mailbox; gathered while the forward pass runs
+            H.is_wmax_put(r.prio, self.st, self.mailbox, self.dist.rank, self.world)
+            wmax_work = self.dist.all_reduce_async(self.mailbox, channel=1)
         fj = self.fj
         # forward. The two nets are STAGGERED, not run side by side: the torso is throughput-bound, the recurrence is
         # latency-bound (32 workgroups), so the target torso runs under the online recurrence and the two recurrences
@@ -387,7 +401,11 @@ class R2D2Engine(ShardedIS):
             with fj.fork(0):                                        # target net: queued behind the online torso
                 self._net_forward(self.Tb, self.Tg, self.tg, self.bsum_tg)
             seq_recurrent_forward(T, B, Hd, self.Pb, self.P, self.on, self.persistent_lstm, bsum=self.bsum_on)
-        H.is_weights(r.prio, self.st, self.w)
+        if wmax_work is not None:
+            wmax_work.wait()
+            H.is_weights(r.prio, self.st, self.w, mailbox=self.mailbox, world=self.world)
+        else:
+            H.is_weights(r.prio, self.st, self.w)
         fj.join()
         H.r2d2_td(self.on.q.view(T, B, A), self.tg.q.view(T, B, A), r.idx, r.act, r.rew, r.done, r.length, self.w, self.st,
                   burn, cfg.nstep, self.done_offset, cfg.gamma_n, cfg.eta, cfg.rescale_eps, self.dq, self.new_prio)
@@ -529,6 +547,20 @@ class R2D2Engine(ShardedIS):
     def _all_reduce(self) -> None:
         if self.dist is not None and self.dist.enabled:
             self.dist.all_reduce_flat(self.G.flat)
+
+    def _global_wmax(self) -> bool:
+        """IS weights normalised by the maximum over ALL ranks' batches: needs a collective in the middle of the forward
+        pass, i.e. one that can sit inside the step graph (the direct xGMI kernel, or RCCL where the start-up trial showed
+        it can be captured) - or no graph at all. With the two-graph schedule (collectives issued between graphs) each
+        rank normalises by its own batch maximum (a per-rank constant scale of its gradient share)."""
+        if self._gw is None:
+            d = self.dist
+            if self.mailbox is None or d is None or not d.enabled:
+                self._gw = False
+            else:
+                xg = getattr(d, "xgmi", None)
+                self._gw = (not self.use_graph) or (bool(d.graph_collectives) and (xg is None or xg.owns(self.mailbox)))
+        return self._gw
 
     def _eager_step(self) -> None:
         self._forward_backward()

@@ -12,8 +12,12 @@ The max-weight normalisation (``weights / weights.max()``, ape_x/learner.py:66-6
 batch of step t + 1 is drawn inside step t, every rank's maximum rides in a small mailbox in front of the flat gradient
 through step t's gradient all-reduce, and the maximum over the ranks is in place one step before the TD kernel reads it
 (engine/apex.py MAILBOX, td.hip k_wmax_put / k_wmax_take; the very first step, drawn at its own start, still uses the
-rank's own maximum). The R2D2 engine normalises per rank (its IS weights and TD sit in the same step as the draw: the
-global maximum would need a collective between them; it scales a rank's loss by a factor close to 1).
+rank's own maximum). The R2D2 engine draws at the start of the step that uses the batch, so its ranks' maxima are
+gathered by a 128-byte all-reduce of the same mailbox that runs UNDER the forward pass (~0.9 ms; the weights are needed
+only by the TD kernel at its end): engine/r2d2.py ``_global_wmax``, td.hip k_is_wmax_put / k_is_weights. That collective
+has to sit inside the step graph - the direct xGMI kernel, or RCCL where the start-up trial allowed capturing it; with the
+two-graph schedule (RCCL issued between graphs) the R2D2 ranks normalise by their own batch maximum, a per-rank constant
+scale of their gradient share.
 """
 from __future__ import annotations
 

@@ -20,7 +20,8 @@ SIGS = {
     "drl_apex_td": [P, P, I, I, P, P, P, P, P, P, F, F, F, F, I, P, P, P, P, P],
     "drl_wmax_put": [P, P, I, I, I, P],
     "drl_wmax_take": [P, P, I, P],
-    "drl_is_weights": [P, I, P, F, P, P],
+    "drl_is_weights": [P, I, P, F, P, P, I, P],
+    "drl_is_wmax_put": [P, I, P, F, P, I, I, I, P],
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
     "drl_grad_sumsq": [P, L, P, POINTER(c_int), P, P, P, P, P, P],

@@ -210,8 +210,21 @@ def wmax_take(st, mailbox: torch.Tensor, world: int) -> None:
     _ck(native.hip().drl_wmax_take(_p(st), _p(mailbox), world, _s()), "wmax_take")
 
 
-def is_weights(p_sampled, st, w_out, n_scale: float = 1.0) -> None:
-    _ck(native.hip().drl_is_weights(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(w_out), _s()), "is_weights")
+def is_weights(p_sampled, st, w_out, n_scale: float = 1.0, mailbox: Optional[torch.Tensor] = None, world: int = 1) -> None:
+    """IS weights of the sampled batch, normalised by their maximum - or, with ``mailbox`` (the ranks' batch maxima, gathered
+    by a SUM all-reduce after ``is_wmax_put``), by the maximum over all ranks' batches."""
+    if mailbox is not None:
+        _chk(mailbox, torch.float32, "mailbox")
+        assert mailbox.numel() >= world
+    _ck(native.hip().drl_is_weights(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(w_out), _p(mailbox), world, _s()),
+        "is_weights")
+
+
+def is_wmax_put(p_sampled, st, mailbox: torch.Tensor, rank: int, world: int, n_scale: float = 1.0) -> None:
+    """The maximum IS weight of this rank's sampled batch -> mailbox[rank], zeros in the other slots (td.hip k_is_wmax_put)."""
+    _chk(mailbox, torch.float32, "mailbox")
+    _ck(native.hip().drl_is_wmax_put(_p(p_sampled), p_sampled.numel(), _p(st), n_scale, _p(mailbox), rank, world, mailbox.numel(),
+                                     _s()), "is_wmax_put")
 
 
 def r2d2_td(q_on, q_tg, idx, act, rew, done, lengths, w, st, burn_in, nstep, done_offset, gamma_n, eta, rs_eps, dq,

@@ -55,11 +55,12 @@ def engine_check(r2d2: bool) -> int:
     torch.cuda.synchronize()
     mine = eng.P.flat.cpu()
     every = [None] * dist.world_size
-    # (the Ape-X engine also agrees on the batch's max IS weight: the ranks' maxima travel with the gradient all-reduce)
-    max_w = None if r2d2 else eng.stats()["max_w"]
+    # both engines also agree on the batch's max IS weight: the ranks' maxima travel with the gradient all-reduce (Ape-X) /
+    # in a 128-byte all-reduce under the forward pass (R2D2)
+    max_w = eng.stats()["max_w"]
     td.all_gather_object(every, (float(mine.double().sum()), float(mine.abs().double().sum()), eng._graphs[0], max_w))
     ok = all(e == every[0] for e in every) and bool(torch.isfinite(mine).all()) and not torch.equal(mine, p0.cpu())
-    ok = ok and (r2d2 or (max_w is not None and max_w > 0))
+    ok = ok and max_w is not None and max_w > 0
     ok = ok and every[0][2] == "one" and all(l == l for l in losses)
     print(json.dumps({"rank": dist.rank, "ok": ok, "sums": every[0][:2], "graph": every[0][2], "loss": losses[-1]}), flush=True)
     dist.barrier()

@@ -182,6 +182,38 @@ def test_apex_td(hip, B, A):
     assert s["loss_cur"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
 
 
+def test_is_weights_with_the_ranks_maxima_from_a_mailbox(hip):
+    """R2D2 data-parallel: k_is_wmax_put writes this rank's batch maximum into its mailbox slot (zeros elsewhere); after the
+    SUM all-reduce (here: a peer's slot filled by hand) k_is_weights normalises by the maximum over all ranks - against
+    oracle.is_weights(max_weight=...)."""
+    H = hip
+    B, cap = 64, 3000
+    g = torch.Generator().manual_seed(9)
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    allp = torch.rand(cap, generator=g) ** 2 + 0.01
+    H.sumtree_ingest(tree, lay, 0, allp.to(DEV), None, torch.zeros(cap, dtype=torch.int32, device=DEV))
+    st = H.new_step_state(DEV, 0.4, 100)
+    n_items = torch.tensor([cap], dtype=torch.int64, device=DEV)
+    idx, p = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, device=DEV)
+    H.sumtree_sample(tree, lay, st, 3, idx, p, begin_n_items=n_items)
+    beta, total = oracle.beta_schedule(0, 0.4, 100), float(allp.double().sum())
+    raw = (cap * p.cpu().double() / total) ** (-beta)
+    mailbox = torch.full((32,), 7.0, device=DEV)
+    H.is_wmax_put(p, st, mailbox, 1, 4)
+    mb = mailbox.cpu()
+    assert mb[1].item() == pytest.approx(float(raw.max()), rel=1e-4) and float(mb.abs().sum()) == pytest.approx(mb[1].item())
+    w = torch.zeros(B, device=DEV)
+    for peer in (0.5 * float(raw.max()), 3.0 * float(raw.max())):    # the peer's batch maximum below / above ours
+        mailbox[2] = peer
+        H.is_weights(p, st, w, mailbox=mailbox, world=4)
+        gmax = torch.tensor(max(peer, float(raw.max())))
+        torch.testing.assert_close(w.cpu(), oracle.is_weights(p.cpu(), total, cap, beta, max_weight=gmax), rtol=2e-4, atol=1e-7)
+        assert H.read_step_state(st)["max_w"] == pytest.approx(float(gmax), rel=1e-4)
+    H.is_weights(p, st, w)                                            # no mailbox: the batch's own maximum
+    torch.testing.assert_close(w.cpu(), oracle.is_weights(p.cpu(), total, cap, beta), rtol=2e-4, atol=1e-7)
+
+
 @pytest.mark.parametrize("B,A", [(512, 4), (50, 18), (33, 6)])
 def test_apex_td_dh_fused_matches_td_plus_head_bwd(hip, B, A):
     """TD + head input gradient in one launch, max IS weight from the sampling kernel, against the single-block TD
