@@ -1031,18 +1031,55 @@ struct TreeExtra {        // host-side description (ctypes mirror: ops/hip.py Tr
     const int* gen;
     const int* gen_expected;
     void* st_end;
+    // gradient-norm partials riding along (single-GPU Ape-X: no launch of their own): sq_blocks more workgroups write the
+    // partial sums of squares of sq_g[0 .. sq_n) to sq_partial[0 .. sq_blocks) and zero zero_g[0 .. zero_n) (a gradient range
+    // the optimizer launch leaves alone because all of its workgroups read it, optim.hip ``late``)
+    const float* sq_g;
+    long long sq_n;
+    float* sq_partial;
+    float* zero_g;
+    long long zero_n;
+    int sq_blocks, pad2;
 };
 
-static_assert(sizeof(TreeExtra) == 120, "TreeExtra is mirrored field by field by ops/hip.py (ctypes)");
+static_assert(sizeof(TreeExtra) == 168, "TreeExtra is mirrored field by field by ops/hip.py (ctypes)");
+
+__device__ __forceinline__ void sumsq_block(const float* __restrict__ g, long long n4, float* __restrict__ partial,
+                                            float* __restrict__ zero_g, long long zero_n4, int block, int n_blocks, float* red) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const long long nt = (long long)n_blocks * NTHREADS;
+    long long i = (long long)block * NTHREADS + threadIdx.x;
+    float acc = 0.f;
+    for (; i + 3 * nt < n4; i += 4 * nt) {                      // four loads in flight per lane
+        const float4 a = g4[i], b = g4[i + nt], c = g4[i + 2 * nt], d = g4[i + 3 * nt];
+        acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        acc += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w + d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    }
+    for (; i < n4; i += nt) {
+        const float4 a = g4[i];
+        acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    for (long long z = (long long)block * NTHREADS + threadIdx.x; z < zero_n4; z += nt)
+        reinterpret_cast<float4*>(zero_g)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[block] = acc;
+}
 
 struct TreeBody {
-    struct Args { TreeDesc tr; const int* idx; const float* val; int n, kind, n2_blocks; const int* gen; const int* gen_expected; StepState* st_end; };
+    struct Args {
+        TreeDesc tr; const int* idx; const float* val; int n, kind, n2_blocks; const int* gen; const int* gen_expected; StepState* st_end;
+        const float* sq_g; long long sq_n4; float* sq_partial; float* zero_g; long long zero_n4; int sq_blocks, tree_blocks;
+    };
     static __device__ __forceinline__ void run(const Args& g, int block, uint8_t* smem) {
+        if (block >= g.tree_blocks) {
+            sumsq_block(g.sq_g, g.sq_n4, g.sq_partial, g.zero_g, g.zero_n4, block - g.tree_blocks, g.sq_blocks, reinterpret_cast<float*>(smem));
+            return;
+        }
         if (g.kind == 1) tree_update_l01_block(g.tr, g.idx, g.val, g.n, g.gen, g.gen_expected, block);
         else if (g.kind == 2) tree_rebuild_upper_block(g.tr, g.n2_blocks, g.st_end, block, reinterpret_cast<float*>(smem));
         else if (block == 0 && threadIdx.x == 0 && g.st_end) g.st_end->step += 1;
     }
-    static int plan(Args& g, const TreeExtra* e, size_t* lds) {
+    static int plan_tree(Args& g, const TreeExtra* e, size_t* lds) {
         g.kind = 0;
         if (!e || e->kind == 0) return 0;
         if (e->n_levels < 1 || e->n_levels > MAX_LEVELS) return -1;
@@ -1057,6 +1094,20 @@ struct TreeBody {
             g.kind = 3;
         }
         return g.st_end ? 1 : 0;
+    }
+    static int plan(Args& g, const TreeExtra* e, size_t* lds) {
+        g.sq_blocks = 0; g.sq_g = nullptr; g.sq_partial = nullptr; g.zero_g = nullptr; g.sq_n4 = g.zero_n4 = 0;
+        const int nt = plan_tree(g, e, lds);
+        if (nt < 0) return nt;
+        g.tree_blocks = nt;
+        if (!e || e->sq_blocks <= 0) { g.tree_blocks = 1 << 30; return nt; }       // every block of this body is a tree block
+        if (!e->sq_g || !e->sq_partial || e->sq_n <= 0 || (e->sq_n & 3) || e->sq_blocks > 1024 || e->zero_n < 0 || (e->zero_n & 3) ||
+            (e->zero_n && !e->zero_g) || ((uintptr_t)e->sq_g & 15) || ((uintptr_t)e->zero_g & 15))
+            return -1;
+        g.sq_g = e->sq_g; g.sq_n4 = e->sq_n >> 2; g.sq_partial = e->sq_partial; g.zero_g = e->zero_g; g.zero_n4 = e->zero_n >> 2;
+        g.sq_blocks = e->sq_blocks;
+        if (*lds < 32 * 4) *lds = 32 * 4;
+        return nt + e->sq_blocks;
     }
 };
 

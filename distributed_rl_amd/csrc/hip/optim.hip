@@ -40,10 +40,17 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// ``late``: the first late_n4 float4 of the gradient are not covered by the partials (they became final only in the launch
+// before this one): every workgroup adds their squares itself (a few KB out of L2).
 __device__ __forceinline__ float clip_coef_from_partials(const float* __restrict__ partial, int n_partial, float grad_scale,
-                                                         float max_norm, float* red, float* norm_out) {
+                                                         float max_norm, float* red, float* norm_out,
+                                                         const float4* __restrict__ late = nullptr, long long late_n4 = 0) {
     float acc = 0.f;
     for (int i = threadIdx.x; i < n_partial; i += blockDim.x) acc += partial[i];
+    for (long long i = threadIdx.x; i < late_n4; i += blockDim.x) {
+        const float4 v = late[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
     acc = block_sum(acc, red);
     const float norm = sqrtf(acc) * grad_scale;
     *norm_out = norm;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
                                                  const float* __restrict__ partial, int n_partial, float grad_scale,
                                                  float max_norm, float lr, float a1, float a2, float eps, StepState* st,
                                                  int zero_grad, int n_opt, CopyExtra cp, const int* __restrict__ fault,
-                                                 long long keep0, long long keep1) {
+                                                 long long keep0, long long keep1, long long late_n4) {
     __shared__ float red[32];
     // optional extra block in front of the update blocks: hands the pre-drawn batch of the next step over (copies)
     const int n_smp = (int)gridDim.x - n_opt;
@@ -93,8 +100,25 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
         }
         return;
     }
+    const long long n4 = n >> 2, stride = (long long)n_opt * blockDim.x;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m14 = reinterpret_cast<float4*>(m1);
+    float4* m24 = reinterpret_cast<float4*>(m2);
+    uint2* pb4 = reinterpret_cast<uint2*>(p_bf16);
+    // the first element's operands are requested BEFORE the norm is reduced (partials, ``late`` range, two block-wide
+    // reductions: ~1.5 us that every workgroup would otherwise spend with nothing in flight), and inside the loop the next
+    // element's operands are requested before the current one is computed
+    long long i = (long long)ob * blockDim.x + threadIdx.x;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pv = z4, gv = z4, mv = z4, vv = z4;
+    if (i < n4) {
+        pv = p4[i]; gv = g4[i]; mv = m14[i];
+        if (MODE == 1) vv = m24[i];
+    }
     float norm;
-    const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm) * grad_scale;
+    const float coef = clip_coef_from_partials(partial, n_partial, grad_scale, max_norm, red, &norm,
+                                               reinterpret_cast<const float4*>(g), late_n4) * grad_scale;
     if (ob == 0 && threadIdx.x == 0 && st) st->grad_norm = norm;
     float bc1 = 1.f, bc2s = 1.f;
     if (MODE == 1) {
@@ -102,22 +126,21 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
         bc1 = 1.0f - __powf(a1, t);
         bc2s = sqrtf(1.0f - __powf(a2, t));
     }
-    const long long n4 = n >> 2;
-    float4* p4 = reinterpret_cast<float4*>(p);
-    float4* g4 = reinterpret_cast<float4*>(g);
-    float4* m14 = reinterpret_cast<float4*>(m1);
-    float4* m24 = reinterpret_cast<float4*>(m2);
-    uint2* pb4 = reinterpret_cast<uint2*>(p_bf16);
-    for (long long i = (long long)ob * blockDim.x + threadIdx.x; i < n4; i += (long long)n_opt * blockDim.x) {
-        float4 pv = p4[i], gv = g4[i];
+    for (; i < n4; i += stride) {
+        const long long nx = i + stride;
+        float4 pn = z4, gn = z4, mn = z4, vn = z4;
+        if (nx < n4) {
+            pn = p4[nx]; gn = g4[nx]; mn = m14[nx];
+            if (MODE == 1) vn = m24[nx];
+        }
         // the split-K / bias-gradient kernels of the NEXT step accumulate with atomics: hand them a zeroed buffer from
         // this pass (the line is in flight anyway) instead of a separate memset launch. Elements [keep0, keep1) are
         // OVERWRITTEN by the next step (plain GEMM outputs: fc1.w, lstm.w_ih / w_hh - 96 % / 92 % of the buffer): no store
-        if (zero_grad && !(i >= keep0 && i < keep1)) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ... and the ``late`` range, which ALL workgroups of this launch read for the norm, is zeroed by a later launch
+        if (zero_grad && !(i >= keep0 && i < keep1) && i >= late_n4) g4[i] = z4;
         float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
         if (MODE == 0) {
-            float4 sv = m14[i];
-            float se[4] = {sv.x, sv.y, sv.z, sv.w};
+            float se[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 se[k] = a1 * se[k] + (1.0f - a1) * ge[k] * ge[k];
@@ -125,7 +148,6 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
             }
             m14[i] = make_float4(se[0], se[1], se[2], se[3]);
         } else {
-            float4 mv = m14[i], vv = m24[i];
             float me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -138,6 +160,7 @@ __global__ __launch_bounds__(256) void k_opt_step(float* __restrict__ p, float* 
         }
         p4[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
         if (p_bf16) pb4[i] = make_uint2(pack_bf2(pe[0], pe[1]), pack_bf2(pe[2], pe[3]));
+        pv = pn; gv = gn; mv = mn; vv = vn;
     }
 }
 
@@ -173,8 +196,11 @@ DRL_API int drl_grad_sumsq(const float* g, long long n, float* partial /* NPART 
 // zero_grad leaves alone (multiples of 4; the caller guarantees that the next step overwrites them).
 DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long long n, const float* partial,
                              int n_partial, float grad_scale, float max_norm, float lr, float alpha, float eps, void* st,
-                             int zero_grad, const void* copies, const int* fault, long long keep0, long long keep1, hipStream_t s) {
-    if (n <= 0 || (n & 3) || (keep0 & 3) || (keep1 & 3)) return -1;
+                             int zero_grad, const void* copies, const int* fault, long long keep0, long long keep1, long long late,
+                             hipStream_t s) {
+    // late (elements, multiple of 4): g[0 .. late) is not covered by ``partial``; the launch sums its squares itself and
+    // leaves it un-zeroed (the caller zeroes it before the next accumulation: TreeExtra::zero_g in gemm.hip)
+    if (n <= 0 || (n & 3) || (keep0 & 3) || (keep1 & 3) || late < 0 || (late & 3) || late > n || late > (1 << 16)) return -1;
     CopyExtra cp;
     cp.n = 0;
     if (copies) {
@@ -182,9 +208,9 @@ DRL_API int drl_rmsprop_step(float* p, float* g, float* sq, void* p_bf16, long l
         if (cp.n < 0 || cp.n > 4) return -2;
         for (int c = 0; c < cp.n; ++c) if (cp.bytes[c] & 15) return -2;
     }
-    const int no = grid_for(n), ns = cp.n > 0 ? 1 : 0;
+    const int no = grid_for(n), ns = cp.n > 0 ? 1 : 0;       // 512 .. 2048 update workgroups: the same 16.3 us
     k_opt_step<0><<<no + ns, 256, 0, s>>>(p, g, sq, nullptr, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm,
-                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2);
+                                          lr, alpha, 0.f, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2, late >> 2);
     return (int)hipGetLastError();
 }
 
@@ -196,7 +222,7 @@ DRL_API int drl_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, 
     cp.n = 0;
     const int no = grid_for(n);
     k_opt_step<1><<<no, 256, 0, s>>>(p, g, m, v, (bf16_t*)p_bf16, n, partial, n_partial, grad_scale, max_norm, lr,
-                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2);
+                                     beta1, beta2, eps, (StepState*)st, zero_grad, no, cp, fault, keep0 >> 2, keep1 >> 2, 0);
     return (int)hipGetLastError();
 }
 

@@ -112,7 +112,8 @@ class ApexEngine(ShardedIS):
 
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
-                 halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True):
+                 halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True,
+                 ride_norm: bool = True):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -180,8 +181,28 @@ class ApexEngine(ShardedIS):
         self.guard = StepGuard(dev)
         if getattr(dist, "xgmi", None) is not None:
             self.guard.add("direct xGMI all-reduce", dist.xgmi.err_ptr())
+        # One rank, no guarded waits: the gradient-norm partials need no launch of their own. A slice of the flat gradient
+        # is final as soon as the launch that produces it has ended, so its sum of squares rides along with the NEXT
+        # backward launch (extra workgroups that fill its tail: ops.hip.tree_extra(sumsq=...)): [conv3.w, end) inside the
+        # conv2 launch, [conv2.w, conv3.w) inside the conv1 launch; what the conv1 launch itself produces ([0, conv2.w) =
+        # 33 KB) every workgroup of the optimizer launch sums itself (``late``). Data-parallel runs keep the norm launch:
+        # their gradients are final only after the all-reduce.
+        o2, o3 = lay.offset("conv2.w"), lay.offset("conv3.w")
+        self._ride_ok = (ride_norm and not self._dist_on() and o2 % 4 == 0 and o3 % 4 == 0 and lay.total % 4 == 0
+                         and (self.G.flat.data_ptr() + 4 * o3) % 16 == 0)
+        nb, ns = 512, 16
+        self._sq_big = (self.G.flat[o3:], self.partial[:nb])
+        self._sq_small = (self.G.flat[o2:o3], self.partial[nb:nb + ns])
+        self._late = o2
+        self._n_partial_ride = nb + ns
 
     # ---- pieces -------------------------------------------------------------------------------------
+    @property
+    def ride_norm(self) -> bool:
+        """Gradient-norm partials inside the backward launches (see __init__)? Not once a guarded wait has been registered:
+        the norm launch is the one that folds the guards into the fault word."""
+        return self._ride_ok and not self.guard.sources
+
     def sync_target(self) -> None:
         self.T.flat.copy_(self.P.flat)
         self.Tb.flat.copy_(self.Pb.flat)
@@ -232,12 +253,15 @@ class ApexEngine(ShardedIS):
         if halo:
             H.conv_halo_dgrad(2, self.d2, self.wt2, a1, self.d1, B)
         H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else self.d1,
-                   B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st))
+                   B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st,
+                                                      sumsq=self._sq_big if self.ride_norm else None,
+                                                      zero=G.flat[:self._late] if self.ride_norm else None))
         # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
         # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
         # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
         H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
-                   splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None)
+                   splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None,
+                   extra=H.tree_extra(0, sumsq=self._sq_small) if self.ride_norm else None)
         if self.mailbox is not None:      # this rank's max IS weight(s) -> mailbox, in front of the conv slice's all-reduce
             H.wmax_put(self.st, self.mailbox, self.dist.rank, self.world)
 
@@ -245,11 +269,13 @@ class ApexEngine(ShardedIS):
         cfg = self.cfg
         if self.mailbox is not None:      # the all-reduces are done: the batch's maximum over ALL ranks
             H.wmax_take(self.st, self.mailbox, self.world)
-        H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
-        H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial, self.n_partial,
-                       1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
+        if not self.ride_norm:
+            H.grad_sumsq(self.G.flat, self.partial, self.guard.sources, self.guard.fault)
+        H.rmsprop_step(self.P.flat, self.G.flat, self.SQ.flat, self.Pb.flat, self.partial,
+                       self._n_partial_ride if self.ride_norm else self.n_partial, 1.0 / self.world, cfg.max_grad_norm, cfg.lr, cfg.rms_alpha, cfg.rms_eps, self.st, zero_grad=True,
                        copies=self.replay.handover_extra() if self.presample else None, fault=self.guard.fault,
-                       keep=self.keep)                       # fc1.w (96 % of the buffer) is overwritten by fc_bwd: no zero store
+                       keep=self.keep,                       # fc1.w (96 % of the buffer) is overwritten by fc_bwd: no zero store
+                       late=self._late if self.ride_norm else 0)
         self.guard.mirror()
         self._primed = self.presample
 

@@ -25,7 +25,7 @@ SIGS = {
     "drl_r2d2_td": [P, P, I, I, I, P, P, P, P, P, P, P, I, I, I, F, F, F, P, P, P, P],
     # optim.hip
     "drl_grad_sumsq": [P, L, P, POINTER(c_int), P, P, P, P, P, P],
-    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P, L, L, P],
+    "drl_rmsprop_step": [P, P, P, P, L, P, I, F, F, F, F, F, P, I, P, P, L, L, L, P],
     "drl_adam_step": [P, P, P, P, P, L, P, I, F, F, F, F, F, F, P, I, P, L, L, P],
     "drl_cast_bf16": [P, P, L, P],
     # head.hip

@@ -273,15 +273,17 @@ def lstm_set_spin_limit(n: int) -> None:
 
 def rmsprop_step(p, g, sq, p_bf16, partial, n_partial, grad_scale, max_norm, lr, alpha, eps, st,
                  zero_grad: bool = False, copies: Optional["CopyExtra"] = None, fault: Optional[torch.Tensor] = None,
-                 keep=(0, 0)) -> None:
+                 keep=(0, 0), late: int = 0) -> None:
     """``zero_grad`` leaves ``g`` zeroed for the next step's atomic accumulation (no separate memset launch) except the
     elements ``keep`` = [a, b), which the caller knows the next step OVERWRITES (plain GEMM outputs). ``copies``
     (see copy_extra) are done by one extra block of the same launch. ``fault`` (see grad_sumsq): non-zero = the step is
-    discarded (nothing but the gradient zeroing and the copies happens)."""
+    discarded (nothing but the gradient zeroing and the copies happens). ``late`` (elements): g[0 .. late) is NOT covered
+    by ``partial`` (gradient-norm partials that rode along with earlier launches, ``tree_extra(sumsq=...)``): every
+    workgroup adds its squares itself, and the range is left un-zeroed (``tree_extra(zero=...)`` does that later)."""
     _ck(native.hip().drl_rmsprop_step(_p(p), _p(g), _p(sq), _p(p_bf16), p.numel(), _p(partial), n_partial, grad_scale,
                                       max_norm, lr, alpha, eps, _p(st), 1 if zero_grad else 0,
-                                      ctypes.byref(copies) if copies is not None else None, _p(fault), keep[0], keep[1], _s()),
-        "rmsprop_step")
+                                      ctypes.byref(copies) if copies is not None else None, _p(fault), keep[0], keep[1], int(late),
+                                      _s()), "rmsprop_step")
 
 
 def adam_step(p, g, m, v, p_bf16, partial, n_partial, grad_scale, max_norm, lr, b1, b2, eps, st,
@@ -763,22 +765,41 @@ class TreeExtra(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n_levels", ctypes.c_int), ("base", ctypes.c_void_p),
                 ("off", ctypes.c_longlong * 6), ("cap", ctypes.c_longlong), ("idx", ctypes.c_void_p),
                 ("val", ctypes.c_void_p), ("n", ctypes.c_int), ("pad", ctypes.c_int), ("gen", ctypes.c_void_p),
-                ("gen_expected", ctypes.c_void_p), ("st_end", ctypes.c_void_p)]
+                ("gen_expected", ctypes.c_void_p), ("st_end", ctypes.c_void_p),
+                ("sq_g", ctypes.c_void_p), ("sq_n", ctypes.c_longlong), ("sq_partial", ctypes.c_void_p),
+                ("zero_g", ctypes.c_void_p), ("zero_n", ctypes.c_longlong), ("sq_blocks", ctypes.c_int), ("pad2", ctypes.c_int)]
 
 
-def tree_extra(kind: int, tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
-               gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
-               end_state: Optional[torch.Tensor] = None) -> TreeExtra:
-    _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
-    assert idx.numel() == val.numel()
+def tree_extra(kind: int, tree: Optional[torch.Tensor] = None, lay: Optional[TreeLayout] = None, idx: Optional[torch.Tensor] = None,
+               val: Optional[torch.Tensor] = None, gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
+               end_state: Optional[torch.Tensor] = None, sumsq=None, zero: Optional[torch.Tensor] = None) -> TreeExtra:
+    """kind 0: no tree stage (only the ride-along work below). ``sumsq`` = (g, partial): partial[b] = sum of squares of
+    workgroup b's share of the fp32 gradient range ``g``, for b < partial.numel() (gradient-norm partials without a launch
+    of their own; the optimizer reads them, ``rmsprop_step(partial, n_partial, late=...)``); ``zero``: an fp32 range the
+    same workgroups set to zero."""
     e = TreeExtra()
-    e.kind, e.n_levels, e.base, e.cap = kind, lay.n_levels, tree.data_ptr(), lay.capacity
-    for i in range(6):
-        e.off[i] = int(lay.offsets[i]) if i < lay.n_levels else 0
-    e.idx, e.val, e.n = idx.data_ptr(), val.data_ptr(), idx.numel()
-    e.gen = gen.data_ptr() if gen is not None else None
-    e.gen_expected = gen_expected.data_ptr() if gen_expected is not None else None
-    e.st_end = end_state.data_ptr() if end_state is not None else None
+    e.kind = kind
+    if kind:
+        _chk(idx, torch.int32, "idx"); _chk(val, torch.float32, "val")
+        assert idx.numel() == val.numel()
+        e.n_levels, e.base, e.cap = lay.n_levels, tree.data_ptr(), lay.capacity
+        for i in range(6):
+            e.off[i] = int(lay.offsets[i]) if i < lay.n_levels else 0
+        e.idx, e.val, e.n = idx.data_ptr(), val.data_ptr(), idx.numel()
+        e.gen = gen.data_ptr() if gen is not None else None
+        e.gen_expected = gen_expected.data_ptr() if gen_expected is not None else None
+        e.st_end = end_state.data_ptr() if end_state is not None else None
+    if sumsq is not None:
+        g, partial = sumsq
+        _chk(g, torch.float32, "sumsq g"); _chk(partial, torch.float32, "sumsq partial")
+        assert g.numel() % 4 == 0 and g.numel() > 0 and 0 < partial.numel() <= 1024 and g.data_ptr() % 16 == 0
+        e.sq_g, e.sq_n, e.sq_partial, e.sq_blocks = g.data_ptr(), g.numel(), partial.data_ptr(), partial.numel()
+        if zero is not None:
+            _chk(zero, torch.float32, "zero")
+            assert zero.numel() % 4 == 0 and zero.data_ptr() % 16 == 0
+            e.zero_g, e.zero_n = zero.data_ptr(), zero.numel()
+    else:
+        assert zero is None
     return e
 
 

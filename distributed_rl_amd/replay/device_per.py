@@ -339,11 +339,13 @@ class DevicePER(RingPair):
         ``end_state`` fuses step_end into the tree rebuild launch."""
         H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
 
-    def update_stage(self, kind: int, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None):
+    def update_stage(self, kind: int, new_prio: torch.Tensor, end_state: Optional[torch.Tensor] = None, sumsq=None, zero=None):
         """The same write-back as ``update`` split into its two stages (kind 1 = leaves + level 1, kind 2 = upper levels +
         optional step_end) as ``TreeExtra`` records: the learner engine hands them to two consecutive fused backward
-        launches (ops.hip.conv_bwd) instead of launching them at the tail of the step."""
-        return H.tree_extra(kind, self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state)
+        launches (ops.hip.conv_bwd) instead of launching them at the tail of the step. ``sumsq`` / ``zero``: gradient-norm
+        partials and a zeroing that ride along in the same record (ops.hip.tree_extra)."""
+        return H.tree_extra(kind, self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state,
+                            sumsq=sumsq, zero=zero)
 
     # host-API parity with PrioritizedMemory (tests / tools; not on the hot path)
     def update_priorities(self, indices, priorities) -> None:
