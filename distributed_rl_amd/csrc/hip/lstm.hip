@@ -56,11 +56,18 @@ __global__ void k_gather_state(const float* __restrict__ src, const int* __restr
     if (dst_bf16) dst_bf16[i] = f2bf(v);
 }
 
-// the stored (h0, c0) of the sampled sequences into the initial-state rows of TWO networks, one launch
+// the stored (h0, c0) of the sampled sequences into the initial-state rows of TWO networks, one launch; the same launch
+// adds up to two pairs of bias vectors (b_ih + b_hh of the online and the target LSTM: they were two launches of their own
+// on the critical path of the R2D2 step, 11 us)
+struct Add2 { const float* a; const float* b; float* out; };
 __global__ void k_gather_state2(const float* __restrict__ h0, const float* __restrict__ c0, const int* __restrict__ idx, int B, int H,
                                 bf16_t* __restrict__ hs_a, float* __restrict__ cs_a, bf16_t* __restrict__ hs_b,
-                                float* __restrict__ cs_b) {
+                                float* __restrict__ cs_b, Add2 s0, Add2 s1, int n_add) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_add) {
+        if (s0.out) s0.out[i] = s0.a[i] + s0.b[i];
+        if (s1.out) s1.out[i] = s1.a[i] + s1.b[i];
+    }
     if (i >= B * H) return;
     int b = i / H, u = i - b * H;
     const long long o = (long long)idx[b] * H + u;
@@ -99,9 +106,14 @@ DRL_API int drl_gather_state(const float* src, const int* idx, int B, int H, flo
     return (int)hipGetLastError();
 }
 DRL_API int drl_gather_state2(const float* h0, const float* c0, const int* idx, int B, int H, void* hs_a, float* cs_a, void* hs_b,
-                              float* cs_b, hipStream_t s) {
-    if (B <= 0 || H <= 0 || !hs_a || !cs_a || (!hs_b) != (!cs_b)) return -1;
-    k_gather_state2<<<(B * H + 255) / 256, 256, 0, s>>>(h0, c0, idx, B, H, (bf16_t*)hs_a, cs_a, (bf16_t*)hs_b, cs_b);
+                              float* cs_b, const float* a0, const float* b0, float* o0, const float* a1, const float* b1, float* o1,
+                              int n_add, hipStream_t s) {
+    if (B <= 0 || H <= 0 || !hs_a || !cs_a || (!hs_b) != (!cs_b) || n_add < 0) return -1;
+    if ((o0 && (!a0 || !b0)) || (o1 && (!a1 || !b1))) return -1;
+    if (!o0 && !o1) n_add = 0;
+    const int n = B * H > n_add ? B * H : n_add;
+    k_gather_state2<<<(n + 255) / 256, 256, 0, s>>>(h0, c0, idx, B, H, (bf16_t*)hs_a, cs_a, (bf16_t*)hs_b, cs_b, Add2{a0, b0, o0},
+                                                    Add2{a1, b1, o1}, n_add);
     return (int)hipGetLastError();
 }
 DRL_API int drl_add2(const float* a, const float* b, float* out, int n, hipStream_t s) {

@@ -95,7 +95,7 @@ def seq_torso_forward(frames: torch.Tensor, frame_off: Optional[torch.Tensor], T
 
 def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int, B: int, Hd: int, net1, net2,
                            steps: Tuple[int, int], persistent: bool, prep=None, free_cus: int = 256,
-                           save_from: Optional[int] = 0) -> None:
+                           save_from: Optional[int] = 0, bias_ready: bool = False) -> None:
     """seq_torso_forward of TWO networks over the SAME frames (R2D2 learner: online + target): the torso of both as one
     launch (the second network's read of a frame finds it in the Infinity Cache); only network 1 keeps act1 / act2, from
     time step ``save_from`` on. net = (wb, wf, buf, bsum)."""
@@ -115,7 +115,7 @@ def seq_torso_forward_dual(frames: torch.Tensor, frame_off: torch.Tensor, T: int
         H.conv_fwd_dual(l, getattr(b1, src)[r0:r1], n, wb1.view(f"conv{l}.w"), wf1.view(f"conv{l}.b"), getattr(b1, dst)[r0:r1],
                         getattr(b2, src)[r0:r1], n, wb2.view(f"conv{l}.w"), wf2.view(f"conv{l}.b"), getattr(b2, dst)[r0:r1],
                         prep=prep if (l == 2 and t0 == 0) else None)
-    if t0 == 0:
+    if t0 == 0 and not bias_ready:                       # (the learner adds them inside its first launch of the step)
         for wb, wf, buf, bsum in (net1, net2):
             H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), bsum)
     if H.use_big_gemm(n, 4 * Hd, 3136):
@@ -330,7 +330,10 @@ class R2D2Engine(ShardedIS):
         # overlap only partly.
         pipelined = self.fwd_chunks > 1 and fj.enabled
         if pipelined:                                               # initial state of both networks, one launch
-            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0])
+            # ... and b_ih + b_hh of both networks (the bias of the input projections), which were two launches of their own
+            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0],
+                            sums=((self.P.view("lstm.b_ih"), self.P.view("lstm.b_hh"), self.bsum_on),
+                                  (self.Tg.view("lstm.b_ih"), self.Tg.view("lstm.b_hh"), self.bsum_tg)))
         else:
             H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0])
         # pre-transformed conv2 / conv3 weights of the LDS-halo input-gradient kernels: written by extra workgroups of the
@@ -353,7 +356,7 @@ class R2D2Engine(ShardedIS):
                     with H.halo_busy(64 if (st_[0] > 0 and self.busy_aware) else 0):
                         seq_torso_forward_dual(r.frames, r.frame_off, T, B, Hd, (self.Pb, self.P, self.on, self.bsum_on),
                                                (self.Tb, self.Tg, self.tg, self.bsum_tg), st_, pl, prep=prep,
-                                               free_cus=256 - 64 * self.fwd_groups_busy(st_), save_from=burn)
+                                               free_cus=256 - 64 * self.fwd_groups_busy(st_), save_from=burn, bias_ready=True)
                 else:
                     seq_torso_forward(r.frames, r.frame_off, T, B, Hd, self.Pb, self.P, self.on, self.bsum_on, steps=st_,
                                       persistent=pl, prep=prep, save_from=burn)
@@ -439,10 +442,13 @@ class R2D2Engine(ShardedIS):
         if self.persistent_bptt and self.bwd_chunks == 2:
             # the persistent chain is faster than the torso backward it feeds: a smaller newest chunk starts the torso
             # earlier (2.49 / 2.44 / 2.43 / 2.45 ms for a cut at window step 64 / 56 / 48 / 40 of 80; more cuts: 2.59-2.61)
-            starts = {0, (3 * L) // 5}
-        cuts_env = self.bwd_cuts                                  # explicit chunk starts in window steps, e.g. "48,64"
+            # (round 3, faster chain in two row groups: 1.706 / 1.683 / 1.658 / 1.688 / 1.820 / 1.738 ms for 40 / 48 / 52 / 56 / 60 /
+            # 64, three chunks 1.88: profiles/r2d2_bwd_cut_sweep_r3.txt)
+            starts = {0, (13 * L) // 20}
+        cuts_env = self.bwd_cuts                                  # explicit chunk starts in window steps: 48, "48,64", (48, 64)
         if cuts_env:
-            starts = {0} | {int(c) for c in cuts_env.split(",") if c.strip() and 0 < int(c) < L}
+            cl = cuts_env.split(",") if isinstance(cuts_env, str) else (cuts_env if isinstance(cuts_env, (tuple, list)) else [cuts_env])
+            starts = {0} | {int(c) for c in cl if str(c).strip() and 0 < int(c) < L}
         order = sorted(starts)
         end_of = {k0: (order[i + 1] if i + 1 < len(order) else L) for i, k0 in enumerate(order)}
         fused_step = self.fused_bptt

@@ -82,7 +82,7 @@ SIGS = {
     "drl_seq_offsets": [P, I, I, L, L, P, P],
     "drl_seq_win_offsets": [P, P, I, I, P, P],
     "drl_gather_state": [P, P, I, I, P, P, P],
-    "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P],
+    "drl_gather_state2": [P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "drl_add2": [P, P, P, I, P],
     # conv_bwd.hip
     "drl_colsum": [P, I, I, P, P],

@@ -956,15 +956,24 @@ def gather_state(src, idx, dst_f32=None, dst_bf16=None) -> None:
     _ck(native.hip().drl_gather_state(_p(src), _p(idx), idx.numel(), src.shape[-1], _p(dst_f32), _p(dst_bf16), _s()), "gather_state")
 
 
-def gather_state2(h0, c0, idx, hs_a, cs_a, hs_b=None, cs_b=None) -> None:
+def gather_state2(h0, c0, idx, hs_a, cs_a, hs_b=None, cs_b=None, sums=()) -> None:
     """Stored recurrent state of the sampled sequences -> initial-state rows (h as bf16, c as fp32) of one or two
-    networks, one launch."""
+    networks, one launch. ``sums``: up to two (a, b, out) triples of equally long fp32 vectors, out = a + b by the same
+    launch (the LSTM's b_ih + b_hh of both networks)."""
     _chk(h0, torch.float32, "h0"); _chk(c0, torch.float32, "c0"); _chk(idx, torch.int32, "idx")
     _chk(hs_a, torch.bfloat16, "hs_a"); _chk(cs_a, torch.float32, "cs_a")
     if hs_b is not None:
         _chk(hs_b, torch.bfloat16, "hs_b"); _chk(cs_b, torch.float32, "cs_b")
+    assert len(sums) <= 2
+    n_add, ptrs = 0, []
+    for a, b, out in sums:
+        _chk(a, torch.float32, "sum a"); _chk(b, torch.float32, "sum b"); _chk(out, torch.float32, "sum out")
+        assert a.numel() == b.numel() == out.numel() and (n_add == 0 or n_add == a.numel())
+        n_add = a.numel()
+        ptrs += [_p(a), _p(b), _p(out)]
+    ptrs += [None] * (6 - len(ptrs))
     _ck(native.hip().drl_gather_state2(_p(h0), _p(c0), _p(idx), idx.numel(), h0.shape[-1], _p(hs_a), _p(cs_a), _p(hs_b), _p(cs_b),
-                                       _s()), "gather_state2")
+                                       *ptrs, n_add, _s()), "gather_state2")
 
 
 def add2(a, b, out) -> None:
