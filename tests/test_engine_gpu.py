@@ -144,6 +144,35 @@ def test_apex_engine_run_steps_equals_single_steps():
     assert dt < 5e-5                                     # the target copies were taken at the same steps
 
 
+def test_apex_engine_norm_partials_in_the_backward_launches_equal_the_norm_launch():
+    """ride_norm (default on one rank): the gradient-norm partials of [conv3.w, end) / [conv2.w, conv3.w) are written by
+    extra workgroups of the conv2 / conv1 backward launches, the optimizer sums conv1's 33 KB itself and leaves that range
+    to be zeroed by the next conv2 launch - against the schedule with the norm launch (k_sumsq_partial), over steps that
+    clip (max_grad_norm far below the norm) so that the norm really enters the update."""
+    _, cfg, rep, e1 = _setup(seed=4, rms_eps=1e-2)
+    _, _, rep2, e2 = _setup(seed=4, rms_eps=1e-2)
+    e1.cfg.max_grad_norm = e2.cfg.max_grad_norm = 1e-3
+    e2._ride_ok = False
+    assert e1.ride_norm and not e2.ride_norm
+    e1.use_graph = e2.use_graph = True
+    for k in range(6):
+        e1.step(); e2.step()
+        s1, s2 = e1.stats(), e2.stats()
+        assert s1["grad_norm"] == pytest.approx(s2["grad_norm"], rel=2e-4) and s1["grad_norm"] > 10 * cfg.max_grad_norm
+    torch.cuda.synchronize()
+    a, b = e1.P.flat.cpu(), e2.P.flat.cpu()
+    d = float((a - b).norm() / a.norm())
+    print("ride-along norm vs norm launch: relative parameter distance %.3e" % d)
+    assert torch.isfinite(a).all() and d < 2e-5
+    # between steps the gradient buffer is zero except what the next step overwrites (fc1.w) and conv1's range, which
+    # the next conv2 launch zeroes before the conv1 launch accumulates into it
+    g = e1.G.flat.clone()
+    k0, k1 = e1.keep
+    g[k0:k1] = 0
+    g[:e1._late] = 0
+    assert float(g.abs().sum()) == 0.0
+
+
 def test_apex_engine_overlapped_allreduce_equals_single_graph(monkeypatch):
     """world_size 1 over real RCCL (DRL_FORCE_DIST=1): the 3-graph step with the two asynchronous all-reduces hidden
     under the conv backward must train exactly like the single-graph step (an all-reduce over one rank is identity)."""
