@@ -16,6 +16,11 @@ its own HBM and trains on its own 512-sample batch; gradients are summed with ON
 kernel inside the step graph when it verifies at start-up, RCCL otherwise - the line says which). A timed step is the
 complete learner iteration: PER sample -> plane windows read from the store -> 3 forwards -> fused TD -> backward ->
 all-reduce -> clip + RMSprop -> priority write-back (target sync included when due).
+
+Timing: the engine is set up (replay filled, step graph captured, ``--settle`` = 1000 steps replayed so that the run is in
+the state of a training job that has been going for a moment; reported as ``extra.settle_steps``), then W warm-up steps,
+then exactly K steps between barrier + synchronize on both sides, max over ranks. ``extra.steady_ms_per_step`` is the same
+step over a window of >= 0.5 s.
 """
 import argparse
 import json
@@ -42,6 +47,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=1000,
+                    help="learner steps replayed right after the step graph has been captured, as part of setting the engine up "
+                         "and BEFORE the --warmup steps: clocks, caches and the allocator reach the state of a run that has "
+                         "been going for a quarter of a second (a 20-step window 5 steps after capture measured 0.206 ms per "
+                         "step where every later window measured 0.199). Reported as extra.settle_steps; 0 turns it off")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--replay", type=int, default=2_000_000, help="transitions per GPU shard")
     ap.add_argument("--n-action", type=int, default=4)
@@ -233,6 +243,10 @@ def run_rank(args) -> int:
 
     eng = eng_s = None
     eng = build_apex(rep, cfg)
+    if args.settle > 0:                                    # same count on every rank: the collectives inside stay matched
+        eng.run_steps(args.settle)
+        torch.cuda.synchronize()
+    extra["settle_steps"] = args.settle
     dt = timed(dist, eng.step, args.steps, args.warmup, many=eng.run_steps)
     ms = 1e3 * dt / args.steps
     updates_s = args.steps / dt
