@@ -55,12 +55,13 @@ def test_epsilon_greedy_single():
 
 
 def test_ctypes_mirrors_of_device_structs():
-    """ops/hip.py mirrors two C structs by hand; the C side pins their sizes with static_asserts (gemm.hip TreeExtra = 120
+    """ops/hip.py mirrors two C structs by hand; the C side pins their sizes with static_asserts (gemm.hip TreeExtra = 168
     bytes, common.h StepState = 64 bytes), this pins the Python side."""
     import ctypes
     from distributed_rl_amd.ops import hip as H
-    assert ctypes.sizeof(H.TreeExtra) == 120
+    assert ctypes.sizeof(H.TreeExtra) == 168
     assert H.TreeExtra.off.offset == 16 and H.TreeExtra.cap.offset == 64 and H.TreeExtra.st_end.offset == 112
+    assert H.TreeExtra.sq_g.offset == 120 and H.TreeExtra.zero_n.offset == 152 and H.TreeExtra.sq_blocks.offset == 160
     assert H.STEP_STATE_BYTES == 64
     lay = H.TreeLayout(2_000_000)
     assert lay.n_levels == 4 and lay.sizes[0] >= 2_000_000 and lay.sizes[-1] == 64 and lay.total == sum(lay.sizes)
