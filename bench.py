@@ -203,7 +203,7 @@ def run_rank(args) -> int:
                               "backend": dist.backend, "device": str(dev)}), flush=True)
         dist.close()
         return 0
-    dist.xgmi_reserve_numel = r2d2_layout(args.n_action).total     # one communication buffer serves both engines
+    dist.xgmi_reserve_numel = r2d2_layout(args.n_action).total + 64    # one communication buffer serves both engines (+ mailbox)
     from distributed_rl_amd.engine.apex import ApexEngine
     from distributed_rl_amd.ops import hip as H
     from distributed_rl_amd.replay.device_per import DevicePER

@@ -330,9 +330,10 @@ class ApexEngine(ShardedIS):
         torch.cuda.synchronize()
         import os
         collective = self.dist is not None and self.dist.enabled
-        if collective and self.dist.graph_collectives:
+        in_graph = collective and self.dist.graph_collectives_for(self.G.flat)
+        if in_graph:
             self.dist.quiesce()        # the watchdog must have retired the warm-up steps' eager collectives (see Dist.quiesce)
-        if not collective or self.dist.graph_collectives:
+        if not collective or in_graph:
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduces (overlapped schedule included) are
             # captured into it as well: no host work at all between sampling and the priority write-back
             g = torch.cuda.CUDAGraph()

@@ -564,8 +564,7 @@ class R2D2Engine(ShardedIS):
             if self.mailbox is None or d is None or not d.enabled:
                 self._gw = False
             else:
-                xg = getattr(d, "xgmi", None)
-                self._gw = (not self.use_graph) or (bool(d.graph_collectives) and (xg is None or xg.owns(self.mailbox)))
+                self._gw = (not self.use_graph) or bool(d.graph_collectives_for(self.G.flat))
         return self._gw
 
     def _eager_step(self) -> None:
@@ -582,9 +581,10 @@ class R2D2Engine(ShardedIS):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         collective = self.dist is not None and self.dist.enabled
-        if collective and self.dist.graph_collectives:
+        in_graph = collective and self.dist.graph_collectives_for(self.G.flat)
+        if in_graph:
             self.dist.quiesce()        # the watchdog must have retired the warm-up steps' eager collectives (see Dist.quiesce)
-        if not collective or self.dist.graph_collectives:
+        if not collective or in_graph:
             # single graph; with DRL_GRAPH_COLLECTIVES=1 the RCCL all-reduce is captured into it as well
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):

@@ -321,16 +321,22 @@ class Dist:
     # ---- collectives inside hipGraphs -------------------------------------------------------------------
     @property
     def graph_collectives(self) -> bool:
-        """May the engines put their collectives INTO the step graph (no host work between graph pieces)?
+        return self.graph_collectives_for(None)
 
-        * direct xGMI all-reduce active: yes - it is an ordinary kernel launch (``DRL_GRAPH_COLLECTIVES=0`` still says no);
+    def graph_collectives_for(self, flat: Optional[torch.Tensor] = None) -> bool:
+        """May an engine put the collectives on its gradient buffer ``flat`` INTO the step graph (no host work between graph
+        pieces)? (``flat=None``: on the direct all-reduce's buffer, if there is one.)
+
+        * ``flat`` lives in the direct xGMI all-reduce's buffer: yes - the collective is an ordinary kernel launch
+          (``DRL_GRAPH_COLLECTIVES=0`` still says no). An engine that did NOT get that buffer (a second engine of the
+          process while the first holds it, or a buffer too small) goes through the process group like any other;
         * RCCL: only on request (``DRL_GRAPH_COLLECTIVES=1``, checked by a captured trial all-reduce that every rank must
           pass). Capturing a library collective races with the process group's watchdog thread (docs/DESIGN.md section 5:
           an eager collective retired less than a polling period before the capture aborts the process), and the only
           guard is a sleep; the default for RCCL is therefore the split schedule - graphs with the collectives issued
           between them - which has no such window."""
         env = os.environ.get("DRL_GRAPH_COLLECTIVES")
-        if self.xgmi is not None and env != "0":
+        if self.xgmi is not None and env != "0" and (flat is None or self.xgmi.owns(flat)):
             return True
         if env != "1":
             if self.enabled and "graph->split" not in " ".join(self.fallbacks):
