@@ -357,6 +357,10 @@ def run_rank(args) -> int:
             dist.broadcast_flat(reng.P.flat)
             H.cast_bf16(reng.P.flat, reng.Pb.flat)
             reng.sync_target()
+            r_settle = min(args.settle, 60)                 # (as for the headline row: capture, then a moment of running)
+            for _ in range(r_settle):
+                reng.step()
+            extra["r2d2_settle_steps"] = r_settle
             r_dt = timed(dist, reng.step, args.r2d2_steps, 3)
             rst = reng.stats()              # the only place a timed-out wait of the persistent kernels becomes an exception
             extra["r2d2_updates_per_s"] = args.r2d2_steps / r_dt
