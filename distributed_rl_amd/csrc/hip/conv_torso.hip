@@ -9,23 +9,24 @@
 // pays its own ramp (weights -> registers, first frame group through an empty pipeline) and tail, and layer l + 1 cannot
 // start before the slowest workgroup of layer l has finished.
 //
-// Structure: persistent 512-thread workgroups, one per CU, one FRAME per round, two roles (by wave number >= 4, the two
-// waves of a SIMD get complementary work - MI355X_MICROARCH "two waves per SIMD" item 9):
-//   waves 0-3 "P": conv1 exactly as conv_direct.hip does it (u8 fragments global -> VGPR in MFMA layout, biased-f16 trick,
-//               all 32 x 256 weights in 64 VGPRs) - but the 16-byte result goes to the LDS image conv2 reads. The 25 output
-//               tiles of a frame are dealt round-robin to the four waves (7 slots each, slot 6 of waves 1-3 repeats tile 24);
-//               slot j's input registers are re-loaded with the NEXT frame's slot j as soon as they are consumed, so every
-//               global load has one whole frame period (> 1 us) to land and nothing is waited for.
-//   waves 4-7 "C": conv2 then conv3 as conv_halo.hip does them (fragments by ds_read_b128 with the tap as the instruction's
-//               immediate, weights in registers, conflict-free padded images), each wave owning 16 of the 64 output
-//               channels of BOTH layers: 64 + 72 weight VGPRs. (The two-MFMAs-per-fragment form of conv_halo.hip - 32
-//               channels per wave - needs 128 + 144 and does not fit next to a second wave on the SIMD.)
-// Round i, two workgroup barriers:
-//   segment A:  P: conv1 tiles 0..15 of frame i+1 -> image1[(i+1) & 1]      C: conv2 of frame i: image1[i & 1] -> image2
-//   segment B:  P: conv1 tiles 16..24 of frame i+1                          C: conv3 of frame i: image2 -> act3 (HBM)
-// P's global loads stay in flight across the barriers (raw s_barrier behind an lgkmcnt-only wait).
-// LDS: 2 x 32 320 (act1 images, pixel pitch 80 B, row pitch 101 slots) + 14 752 (act2 image, pixel pitch 160 B, row pitch
-// 102 slots) = 79 392 B: the layouts of conv_halo.hip (scripts/debug/halo_lds_layout.py).
+// Structure: persistent 512-thread workgroups, one per CU, one FRAME per round, three roles (the two waves of a SIMD get
+// complementary work - MI355X_MICROARCH "two waves per SIMD" item 9), a three-stage pipeline over frames:
+//   waves 0-3 "P":  conv1 of frame j + 1 (biased-f16 trick, all 32 x 256 weights in 64 VGPRs) out of the raw frame that an
+//                LDS-DMA staged one round earlier; the 16-byte result goes to the LDS image conv2 reads. Tiles 0..23 of a
+//                frame are dealt round-robin to the four waves (6 slots each), tile 24 is wave 2's seventh slot.
+//   waves 4-5 "C2": conv2 of frame j (fragments by ds_read_b128 with the tap as the instruction's immediate, weights in
+//                registers, conflict-free padded images as in conv_halo.hip), each wave owning 32 of the 64 output channels:
+//                every fragment read feeds TWO MFMAs.
+//   waves 6-7 "C3": conv3 of frame j - 1, 32 channels per wave, out of the act2 image C2 wrote one round earlier.
+// (Round 3, first form: waves 4-7 each did 16 channels of conv2 AND conv3 of the same frame - 64 + 72 weight VGPRs, two
+// barriers per round, every fragment read by all four waves: the LDS pipe was active 53 % of the kernel's time, 0.67 MB
+// of fragment reads per frame and CU. Splitting by LAYER halves those reads, needs one barrier per round and a second act2
+// image.)
+// Round j = 0 .. nf (one barrier each):  P: frame j + 1 -> image1[(j + 1) & 1]   C2: image1[j & 1] -> image2[j & 1]
+//                                        C3: image2[(j - 1) & 1] -> act3 (HBM)
+// P's LDS-DMAs and global stores stay in flight across the barriers (raw s_barrier behind an lgkmcnt-only wait).
+// LDS: 2 x 32 320 (act1 images, pixel pitch 80 B, row pitch 101 slots) + 2 x 14 752 (act2 images, pixel pitch 160 B, row
+// pitch 102 slots) + 2 x 28 672 (raw frames) = 151 488 B: the image layouts of conv_halo.hip (scripts/debug/halo_lds_layout.py).
 #include "common.h"
 #include "conv_frag.h"
 #include <type_traits>
@@ -45,7 +46,8 @@ struct TorsoNet {
 
 constexpr int T_P1 = 5, T_RP1 = 101, T_IMG1 = 2020 * 16;     // conv2's input image: slots of 16 bytes
 constexpr int T_P2 = 10, T_RP2 = 102, T_IMG2 = 922 * 16;     // conv3's input image
-constexpr int T_RAW = 2 * T_IMG1 + T_IMG2, T_RAWSZ = 28672;   // two raw-frame buffers (28 224 bytes used) behind the images
+constexpr int T_I2 = 2 * T_IMG1;                              // act2 images [2] behind the act1 images [2]
+constexpr int T_RAW = T_I2 + 2 * T_IMG2, T_RAWSZ = 28672;     // two raw-frame buffers (28 224 bytes used) behind the images
 constexpr int T_LDS = T_RAW + 2 * T_RAWSZ;
 
 // every LDS access of this wave has completed, then the workgroup barrier; vector-memory operations stay in flight
@@ -56,7 +58,7 @@ __device__ __forceinline__ void torso_barrier() {
 
 template <bool OFF>
 __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict__ x, TorsoNet n1, TorsoNet n2, HaloPrep prep, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // image1[0], image1[1], image2
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // image1[0..1], image2[0..1], raw[0..1]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     if ((int)blockIdx.x >= n1.nblk + n2.nblk) {                         // the weight pre-pass workgroups (conv_frag.h)
         const int b = (int)blockIdx.x - n1.nblk - n2.nblk;
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
         float4 b4[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<const float4*>(bias + g * 8 + t * 4);
-        // slot j of this wave = output tile min(wave + 4 j, 24): byte offset of the lane's first fragment inside a frame,
-        // of its 16-byte result inside an act1 image, and inside a frame of the act1 array
+        // slot j < 6 of this wave = output tile wave + 4 j; slot 6 = tile 24, computed by wave 2 only: byte offset of the
+        // lane's first fragment inside a frame, of its 16-byte result inside an act1 image, and inside a frame of the act1 array
         int pofs[7], lofs[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -200,9 +202,10 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
                            "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]), "+v"(f[1][3]), "+v"(f[1][4]), "+v"(f[1][5]), "+v"(f[1][6]), "+v"(f[1][7])
                          :: "memory");
         };
-        // groups of a frame: (0, 1) (2, 3) | barrier | (4, 5) (6). The reads of a group are issued before the group in front
-        // of it is computed.
-        auto seg_a = [&](auto save_tag, unsigned raw, unsigned img, int f) __attribute__((always_inline)) {
+        // groups of a frame: (0, 1) (2, 3) (4, 5) and, on wave 2, (6). The reads of a group are issued before the group in
+        // front of it is computed.
+        const bool tail_slot = wave == 2;                // wave-uniform
+        auto conv1_frame = [&](auto save_tag, unsigned raw, unsigned img, int f) __attribute__((always_inline)) {
             rd_slot(fa[0], raw, 0); rd_slot(fa[1], raw, 1);
             land(fa);
             rd_slot(fb_[0], raw, 2); rd_slot(fb_[1], raw, 3);
@@ -210,13 +213,13 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
             land(fb_);
             rd_slot(fa[0], raw, 4); rd_slot(fa[1], raw, 5);
             compute(two_t{}, save_tag, fb_, 2, img, f);
-        };
-        auto seg_b = [&](auto save_tag, unsigned raw, unsigned img, int f) __attribute__((always_inline)) {
             land(fa);
-            rd_slot(fb_[0], raw, 6);
+            if (tail_slot) rd_slot(fb_[0], raw, 6);
             compute(two_t{}, save_tag, fa, 4, img, f);
-            land(fb_);
-            compute(one_t{}, save_tag, fb_, 6, img, f);
+            if (tail_slot) {
+                land(fb_);
+                compute(one_t{}, save_tag, fb_, 6, img, f);
+            }
         };
         // land weights and biases BEFORE the first DMA is issued (their first use would otherwise wait behind the DMAs)
 #pragma unroll
@@ -232,144 +235,168 @@ __global__ __launch_bounds__(512, 1) void k_torso_fwd(const uint8_t* __restrict_
         torso_barrier();                                 // frame 0 is in raw[0]
         {                                                // frame 0 -> image1[0], before the first round
             const int f = frame_of(0);
-            if (f >= save_lo && f < save_hi) { seg_a(std::true_type{}, T_RAW, 0u, f); seg_b(std::true_type{}, T_RAW, 0u, f); }
-            else { seg_a(std::false_type{}, T_RAW, 0u, f); seg_b(std::false_type{}, T_RAW, 0u, f); }
+            if (f >= save_lo && f < save_hi) conv1_frame(std::true_type{}, T_RAW, 0u, f);
+            else conv1_frame(std::false_type{}, T_RAW, 0u, f);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         torso_barrier();                                 // frame 1 is in raw[1], frame 0 in image1[0]
-        for (int i = 0; i < nf; ++i) {
-            // in the last round this is the last frame once more (same values to the same places): no special case
-            const int f = frame_of(i + 1);
-            const unsigned img = ((i + 1) & 1) * T_IMG1, raw = T_RAW + ((i + 1) & 1) * T_RAWSZ;
-            const bool save = f >= save_lo && f < save_hi;      // wave-uniform
-            dma(fbase(frame_of(i + 2)), T_RAW + (i & 1) * T_RAWSZ);   // raw[i & 1] held frame i: read in round i - 1
-            if (!(dbg & 1)) {
-                if (save) seg_a(std::true_type{}, raw, img, f);
-                else seg_a(std::false_type{}, raw, img, f);
+        for (int j = 0; j <= nf; ++j) {
+            if (j + 1 < nf) {                            // wave-uniform: frame j + 1 exists
+                const int f = blk + (j + 1) * nblk;
+                const unsigned img = ((j + 1) & 1) * T_IMG1, raw = T_RAW + ((j + 1) & 1) * T_RAWSZ;
+                const bool save = f >= save_lo && f < save_hi;      // wave-uniform
+                dma(fbase(frame_of(j + 2)), T_RAW + (j & 1) * T_RAWSZ);   // raw[j & 1] held frame j: read in round j - 1
+                if (!(dbg & 1)) {
+                    if (save) conv1_frame(std::true_type{}, raw, img, f);
+                    else conv1_frame(std::false_type{}, raw, img, f);
+                }
+                if (save && !(dbg & 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6) : "memory");   // 6 act1 stores may stay in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            torso_barrier();
-            if (!(dbg & 1)) {
-                if (save) seg_b(std::true_type{}, raw, img, f);
-                else seg_b(std::false_type{}, raw, img, f);
-            }
-            if (save && !(dbg & 1)) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             torso_barrier();
         }
-    } else {
-        // ------------------------------------------- C: conv2, conv3 ----------------------------------------------
-        const int c = wave - 4;                                          // output channels [16 c, 16 c + 16) of both layers
+    } else if (wave < 6) {
+        // ------------------------------------- C2: conv2, 32 channels per wave ------------------------------------
+        const int h = wave - 4;                                          // output channels [32 h, 32 h + 32)
         const bf16_t* __restrict__ w2 = second ? n2.w2 : n1.w2;
-        const bf16_t* __restrict__ w3 = second ? n2.w3 : n1.w3;
         const float* __restrict__ bias2 = second ? n2.b2 : n1.b2;
-        const float* __restrict__ bias3 = second ? n2.b3 : n1.b3;
         bf16_t* __restrict__ act2 = second ? n2.act2 : n1.act2;
-        bf16_t* __restrict__ act3 = second ? n2.act3 : n1.act3;
-        bf16x8 wf2[16], wf3[18];                    // A operand: lane supplies W[channel 16 c + l % 16][k-step s, k = (l / 16) * 8 ..]
+        bf16x8 wf2[2][16];                          // A operand: lane supplies W[channel 32 h + 16 t + l % 16][k-step s, k = (l / 16) * 8 ..]
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wf2[s] = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(16 * c + r) * 512 + s * 32 + g * 8);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 18; ++s) wf3[s] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(16 * c + r) * 576 + s * 32 + g * 8);
-        // the lane ends up with channels 16 c + 4 g .. + 3 of pixel r of every tile
-        float4 bb2 = *reinterpret_cast<const float4*>(bias2 + 16 * c + 4 * g);
-        float4 bb3 = *reinterpret_cast<const float4*>(bias3 + 16 * c + 4 * g);
+            for (int s = 0; s < 16; ++s)
+                wf2[t][s] = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(32 * h + 16 * t + r) * 512 + s * 32 + g * 8);
+        // the lane ends up with channels 32 h + 16 t + 4 g .. + 3 of pixel r of every tile
+        float4 bb2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bb2[t] = *reinterpret_cast<const float4*>(bias2 + 32 * h + 16 * t + 4 * g);
         // rows past the last pixel are computed from the last pixel's inputs and store the same values to the same place
-        unsigned xb2[6], wo2[6], go2[6], xb3[4], go3[4];
+        unsigned xb2[6], wo2[6];                    // (the HBM offset of a tile's result is recomputed where it is stored: registers)
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int m = min(u * 16 + r, 80), oy = m / 9, ox = m - oy * 9;
             xb2[u] = (unsigned)((2 * oy) * T_RP1 + (2 * ox) * T_P1 + g) * 16u;
-            wo2[u] = 2u * T_IMG1 + (unsigned)(oy * T_RP2 + ox * T_P2) * 16u + (unsigned)(32 * c + 8 * g);
-            go2[u] = (unsigned)(m * 128 + 32 * c + 8 * g);
+            wo2[u] = (unsigned)T_I2 + (unsigned)(oy * T_RP2 + ox * T_P2) * 16u + (unsigned)(64 * h + 8 * g);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int m = min(u * 16 + r, 48), oy = m / 7, ox = m - oy * 7;
-            xb3[u] = 2u * T_IMG1 + (unsigned)(oy * T_RP2 + ox * T_P2 + g) * 16u;
-            go3[u] = (unsigned)(m * 128 + 32 * c + 8 * g);
-        }
+        const unsigned go2b = (unsigned)(64 * h + 8 * g);
         // land weights and biases once, here (left to the compiler the waits sit inside the round loop)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(wf2[s]));
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int s = 0; s < 18; ++s) asm volatile("" : "+v"(wf3[s]));
-        asm volatile("" : "+v"(bb2.x), "+v"(bb2.y), "+v"(bb2.z), "+v"(bb2.w), "+v"(bb3.x), "+v"(bb3.y), "+v"(bb3.z), "+v"(bb3.w));
-        __builtin_amdgcn_s_setprio(1);              // the second-dispatched half loses every arbitration otherwise
+            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(wf2[t][s]));
+            asm volatile("" : "+v"(bb2[t].x), "+v"(bb2[t].y), "+v"(bb2[t].z), "+v"(bb2[t].w));
+        }
+        // (no s_setprio: C at priority 1 / P at 2 / both / neither measured 148.0 / 144.9 / 145.7 / 143.4 us on the R2D2 chunk)
         torso_barrier();                            // (P: frame 0 is in raw[0])
         torso_barrier();                            // frame 0 is in image1[0]
-        for (int i = 0; i < nf; ++i) {
-            const int frame = blk + i * nblk;
-            const unsigned cur = (i & 1) * T_IMG1;
-            if (!(dbg & 2))
-            {   // ---- conv2: 6 tiles x 16 k-steps (k-step = one tap of the 4x4 kernel x 32 channels) ----
-                f32x4 acc[6];
+        for (int j = 0; j <= nf; ++j) {
+            if (j < nf && !(dbg & 2)) {
+                // ---- conv2 of frame j: 6 tiles x 16 k-steps (k-step = one tap of the 4x4 kernel x 32 channels) ----
+                const int frame = blk + j * nblk;
+                const unsigned cur = (j & 1) * T_IMG1, out = (j & 1) * T_IMG2;
+                f32x4 acc[2][6];
 #pragma unroll
-                for (int u = 0; u < 6; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 xf[2][6];
-                auto rd = [&](bf16x8 (&dst)[6], int s) __attribute__((always_inline)) {
-                    const int off = ((s >> 2) * T_RP1 + (s & 3) * T_P1) * 16;       // immediate offset of the ds_read
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) dst[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb2[u] + off);
-                };
-                rd(xf[0], 0);
+                    for (int u = 0; u < 6; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 xf[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb2[u]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    if (s + 1 < 16) rd(xf[(s + 1) & 1], s + 1);
+                    const int s1 = s + 1, off = ((s1 >> 2) * T_RP1 + (s1 & 3) * T_P1) * 16;   // immediate offset of the ds_read
 #pragma unroll
                     for (int u = 0; u < 6; ++u) {
-                        acc[u] = torso_mfma(wf2[s], xf[s & 1][u], acc[u]);
-                        // one ds read of k-step s + 1 in the issue gap behind every MFMA of k-step s (a block of 6 reads
-                        // between the MFMA blocks leaves the pipe idle while they issue)
-                        if (s + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        acc[0][u] = torso_mfma(wf2[0][s], xf[u], acc[0][u]);
+                        acc[1][u] = torso_mfma(wf2[1][s], xf[u], acc[1][u]);
+                        // the fragment of k-step s + 1 replaces the one just consumed: one ds read behind every pair of MFMAs
+                        if (s1 < 16) xf[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb2[u] + off);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        if (s1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
-                uint2 o[6];
+                const bool save = frame >= save_lo && frame < save_hi;              // wave-uniform, ONE branch per frame
+                uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(act2) + (long long)frame * 10368;
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    o[u] = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb2.x, 0.f), fmaxf(acc[u][1] + bb2.y, 0.f)),
-                                      pack_bf2(fmaxf(acc[u][2] + bb2.z, 0.f), fmaxf(acc[u][3] + bb2.w, 0.f)));
-                    *reinterpret_cast<uint2*>(smem + wo2[u]) = o[u];
-                }
-                if (frame >= save_lo && frame < save_hi) {                          // wave-uniform, ONE branch per frame
-                    uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(act2) + (long long)frame * 10368;
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int u = 0; u < 6; ++u) *reinterpret_cast<uint2*>(dst + go2[u]) = o[u];
-                }
+                    for (int u = 0; u < 6; ++u) {
+                        const uint2 o = make_uint2(pack_bf2(fmaxf(acc[t][u][0] + bb2[t].x, 0.f), fmaxf(acc[t][u][1] + bb2[t].y, 0.f)),
+                                                   pack_bf2(fmaxf(acc[t][u][2] + bb2[t].z, 0.f), fmaxf(acc[t][u][3] + bb2[t].w, 0.f)));
+                        *reinterpret_cast<uint2*>(smem + out + wo2[u] + 32 * t) = o;
+                        if (save) *reinterpret_cast<uint2*>(dst + (unsigned)min(u * 16 + r, 80) * 128u + go2b + 32 * t) = o;
+                    }
             }
             torso_barrier();
-            if (!(dbg & 4))
-            {   // ---- conv3: 4 tiles x 18 k-steps (k-step = half the 64 channels of one tap of the 3x3 kernel) ----
-                f32x4 acc[4];
+        }
+    } else {
+        // ------------------------------------- C3: conv3, 32 channels per wave ------------------------------------
+        const int h = wave - 6;
+        const bf16_t* __restrict__ w3 = second ? n2.w3 : n1.w3;
+        const float* __restrict__ bias3 = second ? n2.b3 : n1.b3;
+        bf16_t* __restrict__ act3 = second ? n2.act3 : n1.act3;
+        bf16x8 wf3[2][18];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 xf[2][4];
-                auto rd = [&](bf16x8 (&dst)[4], int s) __attribute__((always_inline)) {
-                    const int tap = s >> 1, ky = tap / 3, kx = tap - ky * 3;
-                    const int off = (ky * T_RP2 + kx * T_P2 + (s & 1) * 4) * 16;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const bf16x8*>(smem + xb3[u] + off);
-                };
-                rd(xf[0], 0);
+            for (int s = 0; s < 18; ++s)
+                wf3[t][s] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(32 * h + 16 * t + r) * 576 + s * 32 + g * 8);
+        float4 bb3[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bb3[t] = *reinterpret_cast<const float4*>(bias3 + 32 * h + 16 * t + 4 * g);
+        unsigned xb3[4], go3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = min(u * 16 + r, 48), oy = m / 7, ox = m - oy * 7;
+            xb3[u] = (unsigned)T_I2 + (unsigned)(oy * T_RP2 + ox * T_P2 + g) * 16u;
+            go3[u] = (unsigned)(m * 128 + 64 * h + 8 * g);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s = 0; s < 18; ++s) asm volatile("" : "+v"(wf3[t][s]));
+            asm volatile("" : "+v"(bb3[t].x), "+v"(bb3[t].y), "+v"(bb3[t].z), "+v"(bb3[t].w));
+        }
+        torso_barrier();
+        torso_barrier();
+        for (int j = 0; j <= nf; ++j) {
+            if (j >= 1 && !(dbg & 4)) {
+                // ---- conv3 of frame j - 1: 4 tiles x 18 k-steps (k-step = half the 64 channels of one tap of the 3x3 kernel) ----
+                const int frame = blk + (j - 1) * nblk;
+                const unsigned cur = ((j - 1) & 1) * T_IMG2;
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 xf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb3[u]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                 for (int s = 0; s < 18; ++s) {
-                    if (s + 1 < 18) rd(xf[(s + 1) & 1], s + 1);
+                    const int s1 = s + 1, tap = s1 >> 1, ky = tap / 3, kx = tap - ky * 3;
+                    const int off = (ky * T_RP2 + kx * T_P2 + (s1 & 1) * 4) * 16;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        acc[u] = torso_mfma(wf3[s], xf[s & 1][u], acc[u]);
-                        if (s + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        acc[0][u] = torso_mfma(wf3[0][s], xf[u], acc[0][u]);
+                        acc[1][u] = torso_mfma(wf3[1][s], xf[u], acc[1][u]);
+                        if (s1 < 18) xf[u] = *reinterpret_cast<const bf16x8*>(smem + cur + xb3[u] + off);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        if (s1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
                 uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(act3) + (long long)frame * 6272;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint2 o = make_uint2(pack_bf2(fmaxf(acc[u][0] + bb3.x, 0.f), fmaxf(acc[u][1] + bb3.y, 0.f)),
-                                               pack_bf2(fmaxf(acc[u][2] + bb3.z, 0.f), fmaxf(acc[u][3] + bb3.w, 0.f)));
-                    *reinterpret_cast<uint2*>(dst + go3[u]) = o;
-                }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint2 o = make_uint2(pack_bf2(fmaxf(acc[t][u][0] + bb3[t].x, 0.f), fmaxf(acc[t][u][1] + bb3[t].y, 0.f)),
+                                                   pack_bf2(fmaxf(acc[t][u][2] + bb3[t].z, 0.f), fmaxf(acc[t][u][3] + bb3[t].w, 0.f)));
+                        *reinterpret_cast<uint2*>(dst + go3[u] + 32 * t) = o;
+                    }
             }
             torso_barrier();
         }

@@ -1,6 +1,9 @@
 """Fused torso forward (conv_torso.hip) against the three per-layer launches, at the learners' shapes.
 Usage: python scripts/torso_bench.py [--reps 200]"""
 import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import torch
 from distributed_rl_amd.ops import hip as H
