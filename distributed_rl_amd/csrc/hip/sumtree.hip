@@ -39,6 +39,52 @@ __global__ __launch_bounds__(1024) void k_sample(TreeDesc tr, StepState* st, uns
     sample_block(tr, st, seed, B, idx_out, prio_out, gen, gen_out, frame_off, win, begin_n_items, is_n_scale, blockIdx.x, s_w);
 }
 
+// R2D2 learner: the draw and everything that only depends on it as ONE launch - they were three (k_sample, the window
+// offsets of the drawn sequences, their stored recurrent state into the initial-state rows of both networks) plus two
+// bias-sum launches, 17 + 11 us in front of the first conv of the step. A 256-thread block draws 4 sequences (one wave
+// each, sample_block) and then serves those 4: off[t][b] = win[idx[b]][t] (time-major window offsets for conv1), hs / cs
+// rows of one or two networks from h0 / c0, and - by global thread index - up to two vector sums out = a + b.
+struct SeqAfter {
+    const long long* win; long long* off; int T, H;
+    const float* h0; const float* c0;
+    bf16_t* hs_a; float* cs_a; bf16_t* hs_b; float* cs_b;
+    const float* a0; const float* b0; float* o0; const float* a1; const float* b1; float* o1; int n_add;
+};
+__global__ __launch_bounds__(256) void k_seq_sample(TreeDesc tr, StepState* st, unsigned long long seed, int B,
+                                                   int* __restrict__ idx_out, float* __restrict__ prio_out,
+                                                   const int* __restrict__ gen, int* __restrict__ gen_out,
+                                                   const long long* __restrict__ begin_n_items, SeqAfter a) {
+    __shared__ float s_w[16];
+    __shared__ int s_idx[4];
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi < a.n_add) {
+        if (a.o0) a.o0[gi] = a.a0[gi] + a.b0[gi];
+        if (a.o1) a.o1[gi] = a.a1[gi] + a.b1[gi];
+    }
+    if ((int)blockIdx.x * 4 >= B) return;                       // blocks that exist for the vector sums only
+    sample_block(tr, st, seed, B, idx_out, prio_out, gen, gen_out, nullptr, nullptr, begin_n_items, 0.f, blockIdx.x, s_w);
+    // the four draws of this block: lane 0 of wave w wrote idx_out[4 blk + w]; read it back past the L1 (same address, other wave)
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int b = blockIdx.x * 4 + threadIdx.x;
+        s_idx[threadIdx.x] = b < B ? __hip_atomic_load(idx_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int b = blockIdx.x * 4 + q, i = s_idx[q];
+        if (i < 0) break;
+        for (int t = threadIdx.x; t < a.T; t += 256) a.off[(long long)t * B + b] = a.win[(long long)i * a.T + t];
+        for (int u = threadIdx.x; u < a.H; u += 256) {
+            const long long o = (long long)i * a.H + u, d = (long long)b * a.H + u;
+            const float h = a.h0[o], c = a.c0[o];
+            const bf16_t hb = f2bf(h);
+            a.hs_a[d] = hb; a.cs_a[d] = c;
+            if (a.hs_b) { a.hs_b[d] = hb; a.cs_b[d] = c; }
+        }
+    }
+}
+
 // Leaves <- new priorities (dropped when the slot generation changed since sampling).
 __global__ void k_set_leaves(TreeDesc tr, const int* __restrict__ idx, const float* __restrict__ val, int n,
                              const int* __restrict__ gen, const int* __restrict__ gen_expected) {
@@ -131,6 +177,22 @@ DRL_API int drl_sumtree_sample(float* base, int n_levels, const long long* off, 
     const int wpb = (begin_n_items && is_n_scale > 0.f) ? 16 : 4;           // waves per block (one atomic per block, see kernel)
     k_sample<<<(B + wpb - 1) / wpb, wpb * 64, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, frame_off,
                                                      win, begin_n_items, is_n_scale);
+    return (int)hipGetLastError();
+}
+
+DRL_API int drl_seq_sample(float* base, int n_levels, const long long* off, long long cap, void* st, unsigned long long seed, int B,
+                           int* idx_out, float* prio_out, const int* gen, int* gen_out, const long long* begin_n_items,
+                           const long long* win, long long* frame_off, int T, const float* h0, const float* c0, int H, void* hs_a,
+                           float* cs_a, void* hs_b, float* cs_b, const float* a0, const float* b0, float* o0, const float* a1,
+                           const float* b1, float* o1, int n_add, hipStream_t s) {
+    if (n_levels < 1 || n_levels > MAX_LEVELS || B <= 0 || T <= 0 || H <= 0 || n_add < 0) return -1;
+    if (!idx_out || !prio_out || !win || !frame_off || !h0 || !c0 || !hs_a || !cs_a || (!hs_b) != (!cs_b)) return -1;
+    if ((o0 && (!a0 || !b0)) || (o1 && (!a1 || !b1))) return -1;
+    if (!o0 && !o1) n_add = 0;
+    TreeDesc d = make_desc(base, n_levels, off, cap);
+    SeqAfter a{win, frame_off, T, H, h0, c0, (bf16_t*)hs_a, cs_a, (bf16_t*)hs_b, cs_b, a0, b0, o0, a1, b1, o1, n_add};
+    const int nb = (B + 3) / 4, na = (n_add + 255) / 256;
+    k_seq_sample<<<nb > na ? nb : na, 256, 0, s>>>(d, (StepState*)st, seed, B, idx_out, prio_out, gen, gen_out, begin_n_items, a);
     return (int)hipGetLastError();
 }
 

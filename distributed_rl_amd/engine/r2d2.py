@@ -319,23 +319,25 @@ class R2D2Engine(ShardedIS):
 
     def _forward_backward(self) -> None:
         cfg, r, T, B, Hd, A, L, NB, burn = self.cfg, self.replay, self.T, self.B, self.Hd, self.A, self.L, self.NB, self.burn
-        r.sample(self.st, begin=True, n_is=self.n_is)               # step_begin fused; G was zeroed by the optimizer
+        fj = self.fj
+        pipelined = self.fwd_chunks > 1 and fj.enabled
+        if pipelined:
+            # ONE launch: the draw (step_begin fused; G was zeroed by the optimizer), the window offsets of the drawn
+            # sequences, their stored state into the initial-state rows of both networks, and b_ih + b_hh of both networks
+            # (the bias of the input projections) - five launches in front of the first conv before; worth 0-10 us of the step
+            r.sample_with_state(self.st, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0],
+                                sums=((self.P.view("lstm.b_ih"), self.P.view("lstm.b_hh"), self.bsum_on),
+                                      (self.Tg.view("lstm.b_ih"), self.Tg.view("lstm.b_hh"), self.bsum_tg)), n_is=self.n_is)
+        else:
+            r.sample(self.st, begin=True, n_is=self.n_is)
+            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0])
         wmax_work = None
         if self._global_wmax():             # this rank's batch maximum -> mailbox; gathered while the forward pass runs
             H.is_wmax_put(r.prio, self.st, self.mailbox, self.dist.rank, self.world)
             wmax_work = self.dist.all_reduce_async(self.mailbox, channel=1)
-        fj = self.fj
         # forward. The two nets are STAGGERED, not run side by side: the torso is throughput-bound, the recurrence is
         # latency-bound (32 workgroups), so the target torso runs under the online recurrence and the two recurrences
         # overlap only partly.
-        pipelined = self.fwd_chunks > 1 and fj.enabled
-        if pipelined:                                               # initial state of both networks, one launch
-            # ... and b_ih + b_hh of both networks (the bias of the input projections), which were two launches of their own
-            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0], self.tg.hs[0], self.tg.cs[0],
-                            sums=((self.P.view("lstm.b_ih"), self.P.view("lstm.b_hh"), self.bsum_on),
-                                  (self.Tg.view("lstm.b_ih"), self.Tg.view("lstm.b_hh"), self.bsum_tg)))
-        else:
-            H.gather_state2(r.h0, r.c0, r.idx, self.on.hs[0], self.on.cs[0])
         # pre-transformed conv2 / conv3 weights of the LDS-halo input-gradient kernels: written by extra workgroups of the
         # first conv2 forward launch of the step (or by a launch of their own when that forward is not the halo kernel)
         prep = (self.Pb.view("conv2.w"), self.Pb.view("conv3.w"), self.wt2, self.wt3) if self.halo_bwd else None

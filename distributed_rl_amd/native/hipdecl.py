@@ -9,6 +9,7 @@ SIGS = {
     "drl_step_begin": [P, P, P],
     "drl_step_end": [P, P],
     "drl_sumtree_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, P, P, F, P],
+    "drl_seq_sample": [P, I, LP, L, P, U, I, P, P, P, P, P, P, P, I, P, P, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "drl_sumtree_update": [P, I, LP, L, P, P, I, P, P, P, P, P],
     "drl_sumtree_ingest": [P, I, LP, L, L, I, P, P, P, P, L, P],
     "drl_gather_rows": [P, P, P, I, I, P],

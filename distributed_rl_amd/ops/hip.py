@@ -119,6 +119,35 @@ def sumtree_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: 
                                         float(is_n_scale), _s()), "sumtree_sample")
 
 
+def seq_sample(tree: torch.Tensor, lay: TreeLayout, st: torch.Tensor, seed: int, idx_out: torch.Tensor, prio_out: torch.Tensor,
+               gen: Optional[torch.Tensor], gen_out: Optional[torch.Tensor], begin_n_items: Optional[torch.Tensor],
+               win: torch.Tensor, frame_off: torch.Tensor, T: int, h0: torch.Tensor, c0: torch.Tensor, hs_a, cs_a, hs_b=None,
+               cs_b=None, sums=()) -> None:
+    """``sumtree_sample`` of B sequences + ``seq_win_offsets`` + ``gather_state2`` (+ its vector sums) as ONE launch
+    (sumtree.hip k_seq_sample): the R2D2 learner's first launch of a step."""
+    B = idx_out.numel()
+    _chk(tree, torch.float32, "tree"); _chk(idx_out, torch.int32, "idx_out"); _chk(prio_out, torch.float32, "prio_out")
+    _chk(win, torch.int64, "win"); _chk(frame_off, torch.int64, "frame_off")
+    _chk(h0, torch.float32, "h0"); _chk(c0, torch.float32, "c0"); _chk(hs_a, torch.bfloat16, "hs_a"); _chk(cs_a, torch.float32, "cs_a")
+    Hd = h0.shape[-1]
+    assert win.numel() == lay.capacity * T and frame_off.numel() >= T * B and h0.shape == c0.shape and h0.shape[0] == lay.capacity
+    assert hs_a.numel() >= B * Hd and cs_a.numel() >= B * Hd
+    if hs_b is not None:
+        _chk(hs_b, torch.bfloat16, "hs_b"); _chk(cs_b, torch.float32, "cs_b")
+        assert hs_b.numel() >= B * Hd and cs_b.numel() >= B * Hd
+    assert len(sums) <= 2
+    n_add, ptrs = 0, []
+    for a, b, out in sums:
+        _chk(a, torch.float32, "sum a"); _chk(b, torch.float32, "sum b"); _chk(out, torch.float32, "sum out")
+        assert a.numel() == b.numel() == out.numel() and (n_add == 0 or n_add == a.numel())
+        n_add = a.numel()
+        ptrs += [_p(a), _p(b), _p(out)]
+    ptrs += [None] * (6 - len(ptrs))
+    _ck(native.hip().drl_seq_sample(_p(tree), lay.n_levels, lay.c_off, lay.capacity, _p(st), seed, B, _p(idx_out), _p(prio_out),
+                                    _p(gen), _p(gen_out), _p(begin_n_items), _p(win), _p(frame_off), T, _p(h0), _p(c0), Hd,
+                                    _p(hs_a), _p(cs_a), _p(hs_b), _p(cs_b), *ptrs, n_add, _s()), "seq_sample")
+
+
 def sumtree_update(tree: torch.Tensor, lay: TreeLayout, idx: torch.Tensor, val: torch.Tensor,
                    gen: Optional[torch.Tensor] = None, gen_expected: Optional[torch.Tensor] = None,
                    end_state: Optional[torch.Tensor] = None, fault: Optional[torch.Tensor] = None) -> None:

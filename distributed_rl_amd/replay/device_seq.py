@@ -318,6 +318,15 @@ class DeviceSequenceReplay(RingPair):
                          begin_n_items=(n_is if n_is is not None else self.n_items) if begin else None)
         H.seq_win_offsets(self.idx, self.win, self.T, self.frame_off)
 
+    def sample_with_state(self, st: torch.Tensor, hs_a, cs_a, hs_b=None, cs_b=None, sums=(),
+                          n_is: Optional[torch.Tensor] = None) -> None:
+        """``sample(st, begin=True)`` and what the learner does with the draw right away - the window offsets and the stored
+        recurrent state of the drawn sequences into the initial-state rows of one or two networks (+ up to two vector sums
+        ``out = a + b``) - as ONE launch (ops.hip.seq_sample)."""
+        H.seq_sample(self.tree, self.lay, st, self.seed, self.idx, self.prio, self.gen, self.gen_s,
+                     n_is if n_is is not None else self.n_items, self.win, self.frame_off, self.T, self.h0, self.c0,
+                     hs_a, cs_a, hs_b, cs_b, sums=sums)
+
     def update(self, new_prio: torch.Tensor, end_state=None, fault=None) -> None:
         H.sumtree_update(self.tree, self.lay, self.idx, new_prio, self.gen, self.gen_s, end_state=end_state, fault=fault)
 

@@ -182,6 +182,46 @@ def test_apex_td(hip, B, A):
     assert s["loss_cur"] == pytest.approx(float(td.loss), rel=2e-4) and s["beta"] == pytest.approx(beta, rel=1e-6)
 
 
+@pytest.mark.parametrize("B,T,Hd", [(64, 120, 512), (7, 12, 512), (32, 24, 64)])
+def test_seq_sample_one_launch_equals_the_five_it_replaces(hip, B, T, Hd):
+    """k_seq_sample (draw + window offsets + stored state into both networks' initial rows + two bias sums) against
+    sumtree_sample, seq_win_offsets, gather_state2 and add2 on a copy of the step state: same draws, same everything."""
+    H = hip
+    cap = 1000
+    g = torch.Generator().manual_seed(B + T)
+    lay = H.TreeLayout(cap)
+    tree = torch.zeros(lay.total, device=DEV)
+    H.sumtree_ingest(tree, lay, 0, (torch.rand(cap, generator=g) ** 2 + 1e-3).to(DEV), None, torch.zeros(cap, dtype=torch.int32, device=DEV))
+    win = torch.randint(0, 1 << 40, (cap, T), generator=g, dtype=torch.int64).to(DEV)
+    h0, c0 = torch.randn(cap, Hd, generator=g).to(DEV), torch.randn(cap, Hd, generator=g).to(DEV)
+    gen = torch.randint(0, 9, (cap,), generator=g, dtype=torch.int32).to(DEV)
+    n_items = torch.tensor([cap], dtype=torch.int64, device=DEV)
+    a = [torch.randn(4 * Hd, generator=g).to(DEV) for _ in range(4)]
+    st1 = H.new_step_state(DEV, 0.4, 100)
+    for _ in range(3):
+        H.step_end(st1)
+    st2 = st1.clone()
+
+    def outs():
+        return dict(idx=torch.zeros(B, dtype=torch.int32, device=DEV), prio=torch.zeros(B, device=DEV),
+                    gen_s=torch.zeros(B, dtype=torch.int32, device=DEV), off=torch.zeros(T * B, dtype=torch.int64, device=DEV),
+                    hs_a=torch.zeros(B, Hd, dtype=torch.bfloat16, device=DEV), cs_a=torch.zeros(B, Hd, device=DEV),
+                    hs_b=torch.zeros(B, Hd, dtype=torch.bfloat16, device=DEV), cs_b=torch.zeros(B, Hd, device=DEV),
+                    s0=torch.zeros(4 * Hd, device=DEV), s1=torch.zeros(4 * Hd, device=DEV))
+    o1, o2 = outs(), outs()
+    H.sumtree_sample(tree, lay, st1, 17, o1["idx"], o1["prio"], gen, o1["gen_s"], begin_n_items=n_items)
+    H.seq_win_offsets(o1["idx"], win, T, o1["off"])
+    H.gather_state2(h0, c0, o1["idx"], o1["hs_a"], o1["cs_a"], o1["hs_b"], o1["cs_b"])
+    H.add2(a[0], a[1], o1["s0"]); H.add2(a[2], a[3], o1["s1"])
+    H.seq_sample(tree, lay, st2, 17, o2["idx"], o2["prio"], gen, o2["gen_s"], n_items, win, o2["off"], T, h0, c0,
+                 o2["hs_a"], o2["cs_a"], o2["hs_b"], o2["cs_b"], sums=((a[0], a[1], o2["s0"]), (a[2], a[3], o2["s1"])))
+    torch.cuda.synchronize()
+    assert len(set(o1["idx"].tolist())) > 1
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(st1, st2)                                     # beta, n_items, total priority: the same step_begin
+
+
 def test_is_weights_with_the_ranks_maxima_from_a_mailbox(hip):
     """R2D2 data-parallel: k_is_wmax_put writes this rank's batch maximum into its mailbox slot (zeros elsewhere); after the
     SUM all-reduce (here: a peer's slot filled by hand) k_is_weights normalises by the maximum over all ranks - against
