@@ -174,7 +174,7 @@ class R2D2Engine(ShardedIS):
 
     def __init__(self, n_action: int, cfg: R2D2Config, replay: DeviceSequenceReplay, device="cuda", dist=None,
                  init_model: Optional[DuelingLSTMDQN] = None, use_graph: bool = True, wgrad_splits: int = 128,
-                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks=2, bwd_cuts=None,
+                 done_offset: int = 0, overlap: bool = True, bwd_chunks: int = 2, fwd_chunks=3, bwd_cuts=None,
                  bptt_groups: int = 2, fwd_groups_last: int = 2):
         """Tuning arguments (measured defaults; scripts/r2d2_bench.py --engine-arg sweeps them): ``fwd_chunks`` = number of
         equal time chunks of the pipelined forward or explicit cut points "a,b,.."; ``bwd_chunks`` / ``bwd_cuts`` (chunk starts
@@ -277,6 +277,12 @@ class R2D2Engine(ShardedIS):
             n_ = max(1, int(fc))
             csz_ = (self.T + n_ - 1) // n_
             cuts = list(range(csz_, self.T, csz_))
+            if n_ == 3 and self.T >= 10:
+                # three chunks whose input projections (both networks, 256 x 256 tiles) each take ONE round of tiles on the
+                # CUs a running recurrence leaves free: 1.625 ms per step with two chunks (cut at 64 of 120: the second
+                # chunk's projection, 128 x 128 tiles next to the recurrence, ended 33 us after the first recurrence) ->
+                # 1.601-1.609 with cuts at 44 and 84 (profiles/r2d2_fwd_cut_sweep_r3.txt)
+                cuts = [(11 * self.T) // 30, (7 * self.T) // 10]
             if n_ == 2 and self.T >= 10:
                 # the torso, not the recurrence, bounds the pipelined forward since the recurrence got faster: a larger first
                 # chunk leaves a shorter recurrence after the last torso (2.36 / 2.33 / 2.33 / 2.37 / 2.43 ms per step for a
