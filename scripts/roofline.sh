@@ -14,7 +14,7 @@ A="SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CY
 B="FETCH_SIZE GRBM_GUI_ACTIVE"
 C="WRITE_SIZE GRBM_GUI_ACTIVE"
 for algo in apex r2d2; do
-  if [ $algo = apex ]; then prog="python bench.py --steps 40 --warmup 5 --no-extra --no-graph --no-system"; steps=47
+  if [ $algo = apex ]; then prog="python bench.py --steps 40 --warmup 5 --settle 0 --no-extra --no-graph --no-system"; steps=47
   else prog="python scripts/r2d2_bench.py --steps 6 --warmup 2 --no-graph"; steps=8; fi
   rm -rf $out/tmp
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/tmp -o k -- $prog > $out/$algo.log 2>&1 || { echo "$algo: timing run failed"; tail -3 $out/$algo.log; exit 1; }
