@@ -27,6 +27,15 @@ ARCH = "gfx950"
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=%s" % ARCH, "-ffast-math",
                "-Wno-unused-result", "-munsafe-fp-atomics"]
+# The loss / priority / optimizer arithmetic (TD targets with the value rescale and its inverse, Huber, IS weights, the
+# clip coefficient, RMSprop / Adam) is compiled WITHOUT -ffast-math: IEEE division and square root, no reassociation. These
+# kernels are latency- or HBM-bound, so it costs nothing; the MFMA kernels keep it (their scalar code is address arithmetic
+# and epilogue scaling). Where a kernel wants an approximate transcendental it says so (__powf, __expf).
+PRECISE = {"td.hip", "optim.hip", "head.hip"}
+
+
+def flags_for(src: str) -> List[str]:
+    return [f for f in HIPCC_FLAGS if not (f == "-ffast-math" and os.path.basename(src) in PRECISE)]
 
 
 def _hash(path: str, extra: str = "") -> str:
@@ -72,7 +81,7 @@ def build_hip(force: bool = False, jobs: int = 4, save_temps: bool = False) -> s
     srcs = hip_sources()
     objs, todo = [], []
     for s in srcs:
-        tag = _hash(s, " ".join(HIPCC_FLAGS))
+        tag = _hash(s, " ".join(flags_for(s)))
         obj = os.path.join(BUILD, "%s.%s.o" % (os.path.basename(s)[:-4], tag))
         objs.append(obj)
         if force or not os.path.exists(obj):
@@ -80,7 +89,7 @@ def build_hip(force: bool = False, jobs: int = 4, save_temps: bool = False) -> s
 
     def compile_one(so):
         s, obj = so
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", obj]
+        cmd = [hipcc] + flags_for(s) + ["-c", s, "-o", obj]
         if save_temps:
             cmd.insert(1, "-save-temps=obj")
         _run(cmd)
