@@ -21,6 +21,17 @@ import numpy as np
 from .nstep import NStepBatch, SequenceItem
 
 
+def _load_native_observe():
+    try:
+        from .. import native
+        return native.host().drl_planelog_observe
+    except Exception:  # noqa: BLE001 - no compiler / library: the numpy form does the same
+        return None
+
+
+_native_observe = _load_native_observe()
+
+
 def _weights(n: int, gamma: float, reference_order: bool) -> np.ndarray:
     k = np.arange(n, dtype=np.float64)
     return gamma ** (n - 1 - k) if reference_order else gamma ** k
@@ -38,8 +49,9 @@ class PlaneLog:
     stored correctly; one that does not shift just does not compress. The replay stores transitions as two such positions
     (replay/device_per.py), the wire block carries the planes they span once (transport/codec.py kind 3)."""
 
-    def __init__(self, num_envs: int, cap: int = 512, stack: int = 4):
+    def __init__(self, num_envs: int, cap: int = 512, stack: int = 4, native: bool = True):
         self.E, self.cap, self.stack = num_envs, cap, stack
+        self.native = bool(native) and _native_observe is not None
         self.P: Optional[np.ndarray] = None                   # [E, cap, H, W]
         self.head = np.zeros(num_envs, dtype=np.int64)        # planes appended so far, per env
         self.q = np.zeros(num_envs, dtype=np.int64)           # stream position of the last observation seen
@@ -95,6 +107,14 @@ class PlaneLog:
         one moved on by a frame (one new plane), or something else (all its planes) - and return its stream positions."""
         if self.P is None:
             self.restart(obs)
+            return self.q.copy()
+        if self.native and self.stack == 4 and obs.dtype == np.uint8 and obs.flags.c_contiguous and obs.shape == self._last.shape:
+            # one native pass per env over the two stacks: relation, the new plane(s) into the ring, the copy of the stack
+            # (csrc/host/drl_host.cpp drl_planelog_observe; the numpy form below is its oracle, tests/test_planes_cpu.py)
+            rc = _native_observe(obs.ctypes.data, self._last.ctypes.data, self.P.ctypes.data, self.head.ctypes.data,
+                                 self.q.ctypes.data, self.E, obs.shape[1] * obs.shape[2], self.cap, None)
+            if rc < 0:
+                raise RuntimeError("drl_planelog_observe failed")
             return self.q.copy()
         same, shift = self._relation(obs)
         i = np.nonzero(shift)[0]

@@ -537,6 +537,63 @@ int drl_beat_snapshot(void* h, uint64_t* out, int max_rows) {
 
 int drl_shm_unlink(const char* name) { return shm_unlink(name); }
 
-const char* drl_host_version() { return "drl_host 0.2"; }
+// ---- PlaneLog.observe (algo/vec_assembly.py) for stacks of 4 uint8 planes, all environments of an actor in one call ----
+// Per environment: is the observation the one seen last (nothing happens), that one moved on by ONE frame (its newest
+// plane enters the env's plane ring), or unrelated (all four planes enter)? Decided on the pixels in one pass over the two
+// stacks (numpy: a compare pass + three passes over a scratch array, a strided gather of the new plane and a copy of the
+// stack: 0.5 ms of a 1.3 ms actor tick at 64 envs). obs / last [E][HW][4] u8 (HWC), P [E][cap][HW], head / q [E] int64
+// (planes appended so far / stream position of the current observation), kind_out [E]: 0 same, 1 shifted, 2 restarted.
+// (no clones under the thread sanitizer: their ifunc resolvers run before its runtime is up)
+#if defined(__GNUC__) && !defined(__clang__) && defined(__x86_64__) && !defined(__SANITIZE_THREAD__)
+#define DRL_VEC __attribute__((target_clones("avx2", "default"), optimize("O3")))
+#else
+#define DRL_VEC
+#endif
+DRL_VEC static void plane_relation(const uint32_t* a, const uint32_t* b, int n, uint32_t* d_same, uint32_t* d_shift) {
+    uint32_t ds = 0, dh = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t x = a[i], y = b[i];
+        ds |= x ^ y;
+        dh |= ((y >> 8) ^ x) & 0x00FFFFFFu;                    // planes 0..2 of obs == planes 1..3 of the last one
+    }
+    *d_same = ds; *d_shift = dh;
+}
+DRL_VEC static void plane_extract(const uint32_t* a, int n, int c, uint8_t* dst) {
+    const int sh = 8 * c;
+    for (int i = 0; i < n; ++i) dst[i] = (uint8_t)(a[i] >> sh);
+}
+int drl_planelog_observe(const uint8_t* obs, uint8_t* last, uint8_t* P, int64_t* head, int64_t* q, int E, int HW, int cap,
+                         uint8_t* kind_out) {
+    if (!obs || !last || !P || !head || !q || E <= 0 || HW <= 0 || cap < 4) return -1;
+    int changed = 0;
+    for (int e = 0; e < E; ++e) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(obs + (size_t)e * HW * 4);
+        uint32_t* b = reinterpret_cast<uint32_t*>(last + (size_t)e * HW * 4);
+        uint32_t ds, dh;
+        plane_relation(a, b, HW, &ds, &dh);
+        uint8_t kind = 0;
+        if (ds != 0) {
+            uint8_t* ring = P + (size_t)e * cap * HW;
+            if (dh == 0) {                                      // moved on by one frame: one new plane
+                plane_extract(a, HW, 3, ring + (size_t)(head[e] % cap) * HW);
+                head[e] += 1; q[e] += 1;
+                kind = 1;
+            } else {                                            // unrelated to what the env showed before: all four planes
+                q[e] = head[e];
+                for (int c = 0; c < 4; ++c) {
+                    plane_extract(a, HW, c, ring + (size_t)(head[e] % cap) * HW);
+                    head[e] += 1;
+                }
+                kind = 2;
+            }
+            memcpy(b, a, (size_t)HW * 4);
+            ++changed;
+        }
+        if (kind_out) kind_out[e] = kind;
+    }
+    return changed;
+}
+
+const char* drl_host_version() { return "drl_host 0.3"; }
 
 }  // extern "C"

@@ -26,7 +26,11 @@ def host() -> ctypes.CDLL:
             if not os.path.exists(path) or os.environ.get("DRL_REBUILD_HOST"):
                 path = _build.build_host()
             lib = ctypes.CDLL(path)
-            _declare_host(lib)
+            try:
+                _declare_host(lib)
+            except AttributeError:                      # a library built from an older source: rebuild (seconds) and reload
+                lib = ctypes.CDLL(_build.build_host(force=True))
+                _declare_host(lib)
             _host = lib
     return _host
 
@@ -91,6 +95,7 @@ def _declare_host(lib) -> None:
         "drl_beat_unregister": (None, [c_void_p, c_int]),
         "drl_beat_snapshot": (c_int, [c_void_p, u64p, c_int]),
         "drl_shm_unlink": (c_int, [c_char_p]),
+        "drl_planelog_observe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
         "drl_host_version": (c_char_p, []),
     }
     for name, (res, args) in sig.items():

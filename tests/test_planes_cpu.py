@@ -162,3 +162,40 @@ def test_actor_with_a_non_shifting_env_publishes_short_blocks_instead_of_losing_
     for b in blocks:
         for w in b["win_s2"]:                                     # s' of every transition is a stack the env really showed
             assert np.ascontiguousarray(np.transpose(b["planes"][w:w + 4], (1, 2, 0))).tobytes() in seen
+
+
+def test_native_planelog_observe_equals_the_numpy_form():
+    """csrc/host/drl_host.cpp drl_planelog_observe (one pass per env: relation, new planes into the ring, copy of the stack)
+    against PlaneLog's numpy form on the same stream of observations: unchanged stacks, stacks moved on by one frame, resets
+    (four copies of a frame), unrelated stacks, a stack that differs from a shifted one in ONE pixel of an old plane, and
+    enough steps to wrap the plane ring."""
+    from distributed_rl_amd.algo import vec_assembly as va
+    if va._native_observe is None:
+        pytest.skip("host library not built")
+    E, H, W = 5, 12, 10
+    rng = np.random.default_rng(3)
+    a, b = va.PlaneLog(E, cap=24, native=True), va.PlaneLog(E, cap=24, native=False)
+    assert a.native and not b.native
+    cur = rng.integers(0, 256, (E, H, W, 4), dtype=np.uint8)
+    kinds = set()
+    for t in range(300):
+        nxt = cur.copy()
+        for e in range(E):
+            k = rng.integers(0, 10)
+            if k < 6:                                                    # one new frame
+                nxt[e] = np.concatenate([cur[e][..., 1:], rng.integers(0, 256, (H, W, 1), dtype=np.uint8)], -1)
+            elif k == 6:                                                 # reset: four copies of a first frame
+                nxt[e] = np.repeat(rng.integers(0, 256, (H, W, 1), dtype=np.uint8), 4, -1)
+            elif k == 7:                                                 # unrelated
+                nxt[e] = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+            elif k == 8:                                                 # almost a shift: one pixel of an OLD plane differs
+                nxt[e] = np.concatenate([cur[e][..., 1:], rng.integers(0, 256, (H, W, 1), dtype=np.uint8)], -1)
+                nxt[e][rng.integers(0, H), rng.integers(0, W), rng.integers(0, 3)] ^= 1 << int(rng.integers(0, 8))
+            kinds.add(int(k))
+        cur = np.ascontiguousarray(nxt)
+        qa, qb = a.observe(cur), b.observe(cur)
+        assert np.array_equal(qa, qb) and np.array_equal(a.head, b.head) and np.array_equal(a.q, b.q), t
+        assert np.array_equal(a._last, b._last) and np.array_equal(a.P, b.P), t
+    assert len(kinds) == 10 and int(a.head.min()) > 10 * a.cap           # every case seen, the ring lapped
+    for e in range(E):                                                   # and the current stack reads back from the ring
+        assert np.array_equal(np.moveaxis(a.planes(e, int(a.q[e]), int(a.q[e]) + 3), 0, -1), cur[e])
