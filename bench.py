@@ -91,7 +91,6 @@ def launch_ranks(args, argv) -> int:
         # so the process group is gloo (the JSON line says so - such a number is not a scaling measurement)
         env.setdefault("DRL_SHARE_GPU", "1")
         env.setdefault("DRL_DIST_BACKEND", "gloo")
-        env["DRL_BENCH_REHEARSAL"] = "%d ranks share %d GPU(s), gloo process group" % (args.gpus, n_dev)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
@@ -179,10 +178,6 @@ def run_rank(args) -> int:
     if (not args.no_system and not args.no_extra and not args.check_ranks and args.gpus == 1
             and int(os.environ.get("WORLD_SIZE", "1")) == 1):
         system_rows = run_system_rows(args)
-    wd = float(os.environ.get("DRL_BENCH_WATCHDOG", "0"))
-    if wd > 0:                               # debugging aid: dump every thread's stack and exit if the run takes longer
-        import faulthandler
-        faulthandler.dump_traceback_later(wd, exit=True)
     import torch
     from distributed_rl_amd.config import ApexConfig, R2D2Config
     from distributed_rl_amd.models.packing import r2d2_layout
@@ -215,8 +210,8 @@ def run_rank(args) -> int:
         dist.all_reduce_flat(ones)
         extra["ranks_seen"] = int(ones.item())
         extra["process_group_backend"] = dist.backend
-        if os.environ.get("DRL_BENCH_REHEARSAL"):
-            extra["rehearsal"] = os.environ["DRL_BENCH_REHEARSAL"]
+        if torch.cuda.device_count() < W:      # ranks share devices: such a number is not a scaling measurement
+            extra["rehearsal"] = "%d ranks share %d GPU(s), %s process group" % (W, torch.cuda.device_count(), dist.backend)
 
     # size the shard to the HBM that is actually free: every frame is stored once (replay/device_per.py), ~1.3 planes of
     # 7 KB per transition -> 2 M transitions = 18 GB (as full stacks: 113 GB)

@@ -19,7 +19,6 @@ reference's format.
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
@@ -113,7 +112,7 @@ class ApexEngine(ShardedIS):
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
                  halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True,
-                 ride_norm: bool = True):
+                 ride_norm: bool = True, steps_per_graph: int = 4):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -175,7 +174,7 @@ class ApexEngine(ShardedIS):
         self._grad_cut = lay.offset("fc1.w")             # flat[cut:] = FC1 + head gradients, final after _fb_head
         self._graphs = None
         self._graph_k = None
-        self.steps_per_graph = max(1, int(os.environ.get("DRL_STEPS_PER_GRAPH", "4")))
+        self.steps_per_graph = max(1, int(steps_per_graph))      # K = 4 measured best (2 / 4 / 8 / 16: DESIGN section 2)
         self.steps_done = 0
         # a timed-out poll of the direct xGMI all-reduce must not reach the parameters (engine/guard.py)
         self.guard = StepGuard(dev)

@@ -23,7 +23,7 @@ def host() -> ctypes.CDLL:
     with _lock:
         if _host is None:
             path = _build.HOST_SO
-            if not os.path.exists(path) or os.environ.get("DRL_REBUILD_HOST"):
+            if not os.path.exists(path):
                 path = _build.build_host()
             lib = ctypes.CDLL(path)
             try:

@@ -441,8 +441,9 @@ CONV_HALO_VARIANT = {2: -1, 3: 1}           # -1: by frame count (conv_halo_fwd)
 import contextlib
 
 
-# conv1 -> conv2 -> conv3 of a forward pass as ONE launch (conv_torso.hip). DRL_TORSO_FUSED=0: one launch per layer (A/B).
-TORSO_FUSED = os.environ.get("DRL_TORSO_FUSED", "1") != "0"
+# conv1 -> conv2 -> conv3 of a forward pass as ONE launch (conv_torso.hip). False: one launch per layer - the form the fused
+# kernel is bit-compared with (tests/test_hip_kernels.py, tests/test_engine_gpu.py set it) and the A/B of profiles/bench_r3_torso_*.
+TORSO_FUSED = True
 
 
 @contextlib.contextmanager

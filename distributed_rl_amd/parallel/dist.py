@@ -122,7 +122,7 @@ class Dist:
                     raise RuntimeError("ranks on different hosts")
                 from .xgmi import XgmiAllReduce
                 ar = XgmiAllReduce(cap, self.device, self.rank, self.world_size, group=self.group,
-                                   n_blocks=int(os.environ.get("DRL_XGMI_BLOCKS", "32")), mem_kind=kind)
+                                   n_blocks=32, mem_kind=kind)
                 verified = True
                 ok = self._verify_xgmi(ar, numel)               # keeps the 1 s poll bound: see _agree below
                 if not ok:
@@ -239,8 +239,8 @@ class Dist:
 
     def _time_all_reduces(self, ar, numel: int, iters: int = 20) -> tuple:
         """us per all-reduce of the gradient buffer: (direct kernel at its best grid size, process group), max over
-        ranks. The direct kernel is timed with 16 / 32 / 64 workgroups (a set ``DRL_XGMI_BLOCKS`` pins
-        it) and left at the fastest - identical on every rank, because the decision is taken on all-reduced times."""
+        ranks. The direct kernel is timed with 16 / 32 / 64 workgroups
+        and left at the fastest - identical on every rank, because the decision is taken on all-reduced times."""
         import time
         tmp = torch.zeros(numel, device=self.device)
 
@@ -254,10 +254,7 @@ class Dist:
                 torch.cuda.synchronize(self.device)
             return (time.perf_counter() - t0) / iters * 1e6
 
-        if os.environ.get("DRL_XGMI_BLOCKS"):
-            cands = [ar.n_blocks]
-        else:
-            cands = [16, 32, 64]
+        cands = [16, 32, 64]
         out = []
         for nb in cands:
             ar.set_blocks(nb)

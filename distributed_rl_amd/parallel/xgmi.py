@@ -46,6 +46,7 @@ class XgmiAllReduce:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.rank, self.world, self.device = rank, world, device
+        self.timeout_s = float(timeout_s)
         self.mem_kind, self.n_blocks = mem_kind, int(n_blocks)
         self.cap = (numel + 63) // 64 * 64
         self._ctx = ctypes.c_void_p()
@@ -122,6 +123,7 @@ class XgmiAllReduce:
     def set_timeout(self, seconds: float) -> None:
         """Bound of every flag poll inside the kernel (launches issued after this call)."""
         self._ck(self.lib.drl_xar_set_timeout(self._ctx, float(seconds)), "set_timeout")
+        self.timeout_s = float(seconds)
 
     def err_ptr(self) -> int:
         """Device address of the timeout word (a guard of the optimizer launch, ops.hip.grad_sumsq)."""

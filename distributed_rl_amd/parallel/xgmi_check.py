@@ -62,17 +62,14 @@ def engine_check(r2d2: bool) -> int:
     ok = all(e == every[0] for e in every) and bool(torch.isfinite(mine).all()) and not torch.equal(mine, p0.cpu())
     ok = ok and max_w is not None and max_w > 0
     ok = ok and every[0][2] == "one" and all(l == l for l in losses)
-    print(json.dumps({"rank": dist.rank, "ok": ok, "sums": every[0][:2], "graph": every[0][2], "loss": losses[-1]}), flush=True)
+    print(json.dumps({"rank": dist.rank, "ok": ok, "sums": every[0][:2], "graph": every[0][2], "loss": losses[-1],
+                      "xgmi_timeout_s": dist.xgmi.timeout_s if dist.xgmi is not None else None}), flush=True)
     dist.barrier()
     dist.close()
     return 0 if ok else 1
 
 
 def main() -> int:
-    wd = float(os.environ.get("DRL_BENCH_WATCHDOG", "0"))
-    if wd > 0:                               # debugging aid: dump every thread's stack and exit if the run takes longer
-        import faulthandler
-        faulthandler.dump_traceback_later(wd, exit=True)
     if "--engine" in sys.argv or "--engine-r2d2" in sys.argv:
         return engine_check("--engine-r2d2" in sys.argv)
     ap = argparse.ArgumentParser()

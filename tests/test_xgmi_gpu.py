@@ -20,14 +20,14 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, args):
+def _run_ranks(world, args, **extra_env):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         procs.append(subprocess.Popen([sys.executable, "-m", "distributed_rl_amd.parallel.xgmi_check"] + args,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -55,9 +55,10 @@ def test_xgmi_all_reduce_processes(world):
 @pytest.mark.parametrize("flag", ["--engine", "--engine-r2d2"])
 def test_engine_data_parallel_over_direct_all_reduce(flag):
     """Two learner processes (Ape-X / R2D2), sharded replay, the all-reduce kernels captured in the one-graph step:
-    identical parameters on both ranks after 12 updates."""
-    res = _run_ranks(2, [flag])
-    assert all(r["ok"] and r["graph"] == "one" for r in res)
+    identical parameters on both ranks after 12 updates. DRL_XGMI_TIMEOUT_S: the bound of the kernels' flag polls once the
+    start-up verification (which runs with 1 s) has passed."""
+    res = _run_ranks(2, [flag], DRL_XGMI_TIMEOUT_S="7.5")
+    assert all(r["ok"] and r["graph"] == "one" and r["xgmi_timeout_s"] == 7.5 for r in res)
     assert res[0]["sums"] == res[1]["sums"]
 
 
