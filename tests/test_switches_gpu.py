@@ -41,7 +41,7 @@ def _engines(monkeypatch, fused, **kw):
 
 def test_one_launch_per_layer_is_the_same_step_as_the_fused_torso(monkeypatch):
     """ops.hip.TORSO_FUSED = False (the A/B form of profiles/bench_r3_torso_*): conv1 / conv2 / conv3 as three launches. The
-    fused kernel is bit-identical to them: the first step's Q values and loss are equal bit for bit, and 9 steps end at the
+    fused kernel is bit-identical to them: the first step's Q values are equal bit for bit (its loss up to the order of a float sum), and 9 steps end at the
     same parameters up to the order of the weight gradients' float atomics."""
     out = {}
     for fused in (True, False):
@@ -54,7 +54,7 @@ def test_one_launch_per_layer_is_the_same_step_as_the_fused_torso(monkeypatch):
         torch.cuda.synchronize()
         out[fused] = (first, e.P.flat.clone())
     assert torch.equal(out[True][0][0], out[False][0][0]) and torch.equal(out[True][0][1], out[False][0][1])
-    assert out[True][0][2] == out[False][0][2]
+    assert out[True][0][2] == pytest.approx(out[False][0][2], rel=1e-5)     # (the batch loss is summed with float atomics)
     a, b = out[True][1], out[False][1]
     assert float((a - b).norm() / a.norm()) < 5e-5
 
