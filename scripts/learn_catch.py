@@ -62,7 +62,8 @@ def evaluate(algo, cfg, flat, n_envs=32, ticks=400, seed=123):
     return tot / max(1, balls)
 
 
-def train(algo="ape_x", learner_kind="hip", rounds=30, actor_steps=64, updates=100, n_envs=32, seed=0, lr=None, log=None):
+def train(algo="ape_x", learner_kind="hip", rounds=30, actor_steps=64, updates=100, n_envs=32, seed=0, lr=None, log=None,
+          evals=6, autocast=False):
     torch.manual_seed(seed)
     cfg = make_cfg(algo, lr)
     run_id = "learn-%s-%s-%d" % (algo, learner_kind, os.getpid())
@@ -110,10 +111,13 @@ def train(algo="ape_x", learner_kind="hip", rounds=30, actor_steps=64, updates=1
         actor.run(max_steps=actor_steps)
         if learner_kind == "hip":
             learner.optimize_loop(max_steps=updates, save_model_dir=tmp, warmup_timeout=60)
+        elif autocast:       # the PyTorch learner with bf16 matrix operands (fp32 master weights): what precision alone costs
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                learner.optimize_loop(max_steps=updates, save_model_dir=tmp, start_step=learner.step, warmup_timeout=60)
         else:
             learner.optimize_loop(max_steps=updates, save_model_dir=tmp, start_step=learner.step, warmup_timeout=60)
         publish()
-        if (r + 1) % max(1, rounds // 6) == 0 or r + 1 == rounds:
+        if (r + 1) % max(1, rounds // evals) == 0 or r + 1 == rounds:
             curve.append((r + 1, round(evaluate(algo, cfg, flat()), 3)))
             if log:
                 log("%s/%s round %d: greedy reward per ball %.3f (%.0f s)" % (algo, learner_kind, r + 1, curve[-1][1], time.time() - t0))
@@ -133,6 +137,8 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=32)
     ap.add_argument("--lr", type=float, default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--evals", type=int, default=6, help="evaluations of the greedy policy over the run")
+    ap.add_argument("--autocast", action="store_true", help="torch learner under torch.autocast(bfloat16)")
     a = ap.parse_args()
     print(json.dumps(train(a.algo, a.learner, a.rounds, a.actor_steps, a.updates, a.envs, a.seed, a.lr,
-                           log=lambda s: print(s, flush=True))))
+                           log=lambda s: print(s, flush=True), evals=a.evals, autocast=a.autocast)))

@@ -40,6 +40,27 @@ def _last_values(log_dir):
     return out
 
 
+def _score_curve(log_dir, t0, t1, buckets):
+    """Mean episode score the actors reported ("Score actor_i": ape_x/actor.py:94-99 of the reference sends the same series to
+    visdom) in ``buckets`` equal slices of [t0, t1]: does the running system LEARN while it is being measured?"""
+    out = {}
+    for p in sorted(glob.glob(os.path.join(log_dir, "actor_*.jsonl"))):
+        acc = [[0.0, 0] for _ in range(buckets)]
+        with open(p) as fh:
+            for ln in fh:
+                try:
+                    r = json.loads(ln)
+                except ValueError:
+                    continue
+                if r["name"].startswith("Score ") and t0 <= r["t"] < t1:
+                    b = acc[min(buckets - 1, int((r["t"] - t0) / (t1 - t0) * buckets))]
+                    b[0] += r["y"]
+                    b[1] += 1
+        out[os.path.basename(p)[:-6]] = [[round((i + 0.5) * (t1 - t0) / buckets, 1), round(a / n, 3) if n else None, n]
+                                         for i, (a, n) in enumerate(acc)]
+    return out
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--algorithm", default="ape_x", choices=["ape_x", "r2d2"])
@@ -50,6 +71,8 @@ def main(argv=None) -> int:
     ap.add_argument("--warmup-seconds", type=float, default=3.0)
     ap.add_argument("--replay", type=int, default=0, help="replay capacity (0: 200 000 transitions / 4 096 sequences)")
     ap.add_argument("--actor-engine", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--score-buckets", type=int, default=0,
+                    help="also report the actors' mean episode score in this many slices of the run (is the system learning?)")
     args = ap.parse_args(argv)
 
     import torch
@@ -84,7 +107,7 @@ def main(argv=None) -> int:
     result = {"algorithm": args.algorithm, "actors": args.actors, "envs_per_actor": args.envs, "env": args.env,
               "actor_engine": args.actor_engine, "replay_capacity": cap}
     stop = threading.Event()
-    marks = {}
+    marks = {"t0": time.time()}
 
     def actor_steps():
         return sum(r["progress"] for r in hb_table.snapshot() if r["role"] == "actor")
@@ -138,6 +161,9 @@ def main(argv=None) -> int:
             "actor_phase_ms": {k.split(" ", 2)[2]: round(v, 3) for k, v in last.items() if k.startswith("Phase ms actor/")
                                and k.endswith("actor_1")},
         })
+        if args.score_buckets > 0:
+            result["score_curve_s_mean_n"] = _score_curve(log_dir, marks["t0"], tb, args.score_buckets)
+            result["learner_updates_total"] = learner.step
     except Exception as e:  # noqa: BLE001
         result["error"] = repr(e)[:300]
         rc = 1
