@@ -73,7 +73,10 @@ def main(argv=None) -> int:
     ap.add_argument("--actor-engine", default="hip", choices=["hip", "torch"])
     ap.add_argument("--score-buckets", type=int, default=0,
                     help="also report the actors' mean episode score in this many slices of the run (is the system learning?)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES of the LEARNER process (0: leave the default)")
     args = ap.parse_args(argv)
+    if args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)          # read when the HIP runtime starts: before torch touches the GPU
 
     import torch
     from distributed_rl_amd import envs
@@ -97,6 +100,8 @@ def main(argv=None) -> int:
     learner.publish(wait=True)
 
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DRL_ACTOR_REPORT_S="1.0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if args.hw_queues:
+        env.pop("GPU_MAX_HW_QUEUES", None)
     procs = []
     for i in range(1, args.actors + 1):
         procs.append(subprocess.Popen(
