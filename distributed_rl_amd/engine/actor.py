@@ -142,22 +142,41 @@ class ActorEngine:
         K, M = int(action.shape[0]), int(planes.shape[0])
         dev = self.device
         if getattr(self, "_ppk", (0, 0))[0] != K or self._ppk[1] < M:
-            self._ppk = (K, max(M, 2 * K))
+            # ONE pinned staging buffer and ONE device image of it: [offsets 2K x i64 | action K x i32 | reward K x f32 |
+            # done K x f32 | plane pool]; a block costs one host-to-device DMA instead of five pageable copies
+            cap = max(M, 2 * K)
+            self._ppk = (K, cap)
+            tab = (16 * K + 3 * 4 * K + 63) // 64 * 64
+            self._pptab = tab
+            self._pppin = torch.zeros(tab + cap * 84 * 84, dtype=torch.uint8).pin_memory()
+            self._ppdev = torch.zeros(tab + cap * 84 * 84, dtype=torch.uint8, device=dev)
+            self._pph = self._pppin.numpy()
+
+            def views(buf):
+                return (buf[:16 * K].view(torch.int64), buf[16 * K:20 * K].view(torch.int32),
+                        buf[20 * K:24 * K].view(torch.float32), buf[24 * K:28 * K].view(torch.float32), buf[tab:].view(cap, 84 * 84))
+            self._ppoff, self._ppa, self._ppr, self._ppd, self._pplanes = views(self._ppdev)
             self._ppbuf = TorsoBuffers(2 * K, self.A, dev)
-            self._pplanes = torch.zeros(self._ppk[1], 84 * 84, dtype=torch.uint8, device=dev)
-            self._ppoff = torch.zeros(2 * K, dtype=torch.int64, device=dev)
             self._pdq2 = torch.zeros(K, self.A, device=dev)
             self._pprio2 = torch.zeros(K, device=dev)
-        self._pplanes[:M].copy_(torch.from_numpy(np.ascontiguousarray(planes).reshape(M, -1)), non_blocking=True)
-        off = np.concatenate([win_s, win_s2]).astype(np.int64) * (84 * 84)
-        self._ppoff.copy_(torch.from_numpy(off), non_blocking=True)
+            self._pprio_pin = torch.zeros(K, dtype=torch.float32).pin_memory()
+        h, tab = self._pph, self._pptab
+        off = h[:16 * K].view(np.int64)
+        off[:K] = win_s
+        off[K:] = win_s2
+        off *= 84 * 84
+        h[16 * K:20 * K].view(np.int32)[:] = action
+        h[20 * K:24 * K].view(np.float32)[:] = reward
+        h[24 * K:28 * K].view(np.float32)[:] = done
+        h[tab:tab + M * 84 * 84] = planes.reshape(-1)
+        n = tab + M * 84 * 84
+        self._ppdev[:n].copy_(self._pppin[:n], non_blocking=True)
         torso_forward(self._pplanes, self._ppoff, 2 * K, self.Pb, self.P, self._ppbuf)
-        a = torch.from_numpy(np.ascontiguousarray(action, dtype=np.int32)).to(dev)
-        r = torch.from_numpy(np.ascontiguousarray(reward, dtype=np.float32)).to(dev)
-        d = torch.from_numpy(np.ascontiguousarray(done, dtype=np.float32)).to(dev)
-        H.apex_td(self._ppbuf.q, self._ppbuf.q[K:], None, a, r, d, None, self.st, gamma_n, alpha, prio_eps, self._pdq2,
-                  self._pprio2, use_is=False)
-        return self._pprio2.cpu().numpy()
+        H.apex_td(self._ppbuf.q, self._ppbuf.q[K:], None, self._ppa, self._ppr, self._ppd, None, self.st, gamma_n, alpha, prio_eps,
+                  self._pdq2, self._pprio2, use_is=False)
+        self._pprio_pin.copy_(self._pprio2, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._pprio_pin.numpy().copy()
 
     # ---- benchmarks -------------------------------------------------------------------------------------
     def step_synthetic(self) -> None:
