@@ -141,42 +141,43 @@ class ActorEngine:
         2 K stacks of 28 KB) and conv1 reads the windows in place, as the learner does from its replay."""
         K, M = int(action.shape[0]), int(planes.shape[0])
         dev = self.device
-        if getattr(self, "_ppk", (0, 0))[0] != K or self._ppk[1] < M:
+        if getattr(self, "_ppk", (0, 0))[0] < K or self._ppk[1] < M:
             # ONE pinned staging buffer and ONE device image of it: [offsets 2K x i64 | action K x i32 | reward K x f32 |
-            # done K x f32 | plane pool]; a block costs one host-to-device DMA instead of five pageable copies
-            cap = max(M, 2 * K)
-            self._ppk = (K, cap)
-            tab = (16 * K + 3 * 4 * K + 63) // 64 * 64
+            # done K x f32 | plane pool]; a block costs one host-to-device DMA instead of five pageable copies. Sized for the
+            # largest block seen (shorter blocks - an env that publishes early, runtime/actor.py _urgent_envs - use a prefix)
+            Kc, cap = max(K, getattr(self, "_ppk", (0, 0))[0]), max(M, 2 * K, getattr(self, "_ppk", (0, 0))[1])
+            self._ppk = (Kc, cap)
+            tab = (28 * Kc + 63) // 64 * 64
             self._pptab = tab
             self._pppin = torch.zeros(tab + cap * 84 * 84, dtype=torch.uint8).pin_memory()
             self._ppdev = torch.zeros(tab + cap * 84 * 84, dtype=torch.uint8, device=dev)
             self._pph = self._pppin.numpy()
-
-            def views(buf):
-                return (buf[:16 * K].view(torch.int64), buf[16 * K:20 * K].view(torch.int32),
-                        buf[20 * K:24 * K].view(torch.float32), buf[24 * K:28 * K].view(torch.float32), buf[tab:].view(cap, 84 * 84))
-            self._ppoff, self._ppa, self._ppr, self._ppd, self._pplanes = views(self._ppdev)
-            self._ppbuf = TorsoBuffers(2 * K, self.A, dev)
-            self._pdq2 = torch.zeros(K, self.A, device=dev)
-            self._pprio2 = torch.zeros(K, device=dev)
-            self._pprio_pin = torch.zeros(K, dtype=torch.float32).pin_memory()
+            d_ = self._ppdev
+            self._ppoff, self._ppa = d_[:16 * Kc].view(torch.int64), d_[16 * Kc:20 * Kc].view(torch.int32)
+            self._ppr, self._ppd = d_[20 * Kc:24 * Kc].view(torch.float32), d_[24 * Kc:28 * Kc].view(torch.float32)
+            self._pplanes = d_[tab:].view(cap, 84 * 84)
+            self._ppbuf = TorsoBuffers(2 * Kc, self.A, dev)
+            self._pdq2 = torch.zeros(Kc, self.A, device=dev)
+            self._pprio2 = torch.zeros(Kc, device=dev)
+            self._pprio_pin = torch.zeros(Kc, dtype=torch.float32).pin_memory()
+        Kc = self._ppk[0]
         h, tab = self._pph, self._pptab
-        off = h[:16 * K].view(np.int64)
+        off = h[:16 * K].view(np.int64)                       # [win_s | win_s2] as byte offsets: the first 2 K of the table
         off[:K] = win_s
         off[K:] = win_s2
         off *= 84 * 84
-        h[16 * K:20 * K].view(np.int32)[:] = action
-        h[20 * K:24 * K].view(np.float32)[:] = reward
-        h[24 * K:28 * K].view(np.float32)[:] = done
+        h[16 * Kc:16 * Kc + 4 * K].view(np.int32)[:] = action
+        h[20 * Kc:20 * Kc + 4 * K].view(np.float32)[:] = reward
+        h[24 * Kc:24 * Kc + 4 * K].view(np.float32)[:] = done
         h[tab:tab + M * 84 * 84] = planes.reshape(-1)
         n = tab + M * 84 * 84
         self._ppdev[:n].copy_(self._pppin[:n], non_blocking=True)
-        torso_forward(self._pplanes, self._ppoff, 2 * K, self.Pb, self.P, self._ppbuf)
-        H.apex_td(self._ppbuf.q, self._ppbuf.q[K:], None, self._ppa, self._ppr, self._ppd, None, self.st, gamma_n, alpha, prio_eps,
-                  self._pdq2, self._pprio2, use_is=False)
-        self._pprio_pin.copy_(self._pprio2, non_blocking=True)
+        torso_forward(self._pplanes, self._ppoff[:2 * K], 2 * K, self.Pb, self.P, self._ppbuf)
+        H.apex_td(self._ppbuf.q[:2 * K], self._ppbuf.q[K:2 * K], None, self._ppa[:K], self._ppr[:K], self._ppd[:K], None, self.st, gamma_n,
+                  alpha, prio_eps, self._pdq2[:K], self._pprio2[:K], use_is=False)
+        self._pprio_pin[:K].copy_(self._pprio2[:K], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return self._pprio_pin.numpy().copy()
+        return self._pprio_pin[:K].numpy().copy()
 
     # ---- benchmarks -------------------------------------------------------------------------------------
     def step_synthetic(self) -> None:

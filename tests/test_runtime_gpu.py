@@ -46,12 +46,14 @@ def test_actor_engine_matches_module():
     np.testing.assert_allclose(pr, td.prio.detach().numpy(), rtol=0.15, atol=0.03)
     # the same priorities from a plane-pool block (codec kind 3: every frame once + two window positions per transition, one
     # staging buffer / one DMA per block); blocks of different pool sizes reuse the buffers
-    for M in (K + 9, K + 5, 3 * K):
+    # (and shorter blocks - an env that publishes early - a prefix of them)
+    for M, k in ((K + 9, K), (K + 5, K), (3 * K, K), (12, 7), (40, K)):
         planes = rng.integers(0, 256, (M, 84, 84), dtype=np.uint8)
-        ws, ws2 = rng.integers(0, M - 3, K), rng.integers(0, M - 3, K)
+        ws, ws2 = rng.integers(0, M - 3, k), rng.integers(0, M - 3, k)
         st = lambda w: np.ascontiguousarray(np.transpose(planes[w[:, None] + np.arange(4)], (0, 2, 3, 1)))    # noqa: E731
-        pr_planes = eng.priorities_planes(planes, ws, ws2, act, rew, done, 0.99, 0.6)
-        pr_stacks = eng.priorities(st(ws), st(ws2), act, rew, done, 0.99, 0.6)
+        pr_planes = eng.priorities_planes(planes, ws, ws2, act[:k], rew[:k], done[:k], 0.99, 0.6)
+        pr_stacks = eng.priorities(st(ws), st(ws2), act[:k], rew[:k], done[:k], 0.99, 0.6)
+        assert pr_planes.shape == (k,)
         np.testing.assert_allclose(pr_planes, pr_stacks, rtol=2e-2, atol=2e-3)
     # parameter refresh from a flat buffer
     m2 = DuelingDQN(6)
