@@ -117,6 +117,15 @@ def main(argv=None) -> int:
     def actor_steps():
         return sum(r["progress"] for r in hb_table.snapshot() if r["role"] == "actor")
 
+    def rss_mb():
+        """Resident set of the learner (this process) and of the actor processes, MB: a soak's leak check."""
+        try:
+            import psutil
+            return [round(psutil.Process(os.getpid()).memory_info().rss / 2 ** 20)] + \
+                   [round(psutil.Process(p.pid).memory_info().rss / 2 ** 20) for p in procs if p.poll() is None]
+        except Exception:  # noqa: BLE001
+            return []
+
     def clock():
         """Marks the start and the end of the measurement window while the learner loop runs in the main thread."""
         t_begin = time.time()
@@ -128,7 +137,17 @@ def main(argv=None) -> int:
             time.sleep(0.05)
         time.sleep(args.warmup_seconds)
         marks["a"] = (time.time(), learner.step, learner.ingested, actor_steps(), exp.stats())
-        time.sleep(args.seconds)
+        marks["rss_a"] = rss_mb()
+        halves = []
+        for _ in range(2):                                   # the rate of each half of the window: does it hold?
+            s0, t0_ = learner.step, time.time()
+            while time.time() - t0_ < args.seconds / 2:
+                time.sleep(min(30.0, max(0.0, args.seconds / 2 - (time.time() - t0_))))
+                print("[system_bench] %.0f s: learner step %d, %d items ingested" % (time.time() - marks["t0"], learner.step,
+                                                                                      learner.ingested), file=sys.stderr, flush=True)
+            halves.append(round((learner.step - s0) / (time.time() - t0_)))
+        marks["halves"] = halves
+        marks["rss_b"] = rss_mb()
         marks["b"] = (time.time(), learner.step, learner.ingested, actor_steps(), exp.stats())
         marks["versions"] = par.version()
         stop.set()
@@ -161,6 +180,8 @@ def main(argv=None) -> int:
             "param_versions_published": marks["versions"],
             "param_version_lag_max": max(lag) if lag else None,
             "replay_items": len(learner.replay),
+            "learner_updates_per_s_by_half": marks.get("halves"),
+            "rss_mb_learner_then_actors": {"start": marks.get("rss_a"), "end": marks.get("rss_b")},
             "ingest": learner.pipe.stats() if learner.pipe is not None else "synchronous",
             "learner_phase_ms": {k: round(v["mean_ms"], 4) for k, v in learner.metrics_local.phase_report().items()},
             "actor_phase_ms": {k.split(" ", 2)[2]: round(v, 3) for k, v in last.items() if k.startswith("Phase ms actor/")
