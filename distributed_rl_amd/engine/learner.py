@@ -114,6 +114,8 @@ class _AsyncPublisher:
 
 
 class HipLearner:
+    sync_every = 4096            # learner steps between two device-wide synchronizes of optimize_loop (see there)
+
     def __init__(self, algorithm: str, n_action: int, cfg, exp: ExperienceChannel, params: ParamChannel, metrics=None,
                  replay_size: int = 100_000, device="cuda", heartbeat=None, dist=None, use_graph: bool = True,
                  publish_interval: float = 0.05, max_blocks_per_step: int = 8, seed: int = 0, save_replay: bool = False,
@@ -304,7 +306,16 @@ class HipLearner:
 
         def clear_of_duties(t: int) -> bool:
             return all((t % p == 0 and K <= p) or (t % p) + K <= p for p in periods)
+        # A loop that only ever waits for EVENTS lets the HIP runtime's host-side records of finished launches pile up:
+        # 2.6 KB per R2D2 step (a graph of ~50 kernels on four streams), 1.6 MB/s, 5.6 GB per hour of resident memory
+        # (scripts/debug/learner_rss.py; with a device-wide synchronize now and then: flat). Every SYNC_EVERY steps the loop
+        # therefore drains the device once - the run-ahead of three loop turns, a few ms every ~7 s.
+        SYNC_EVERY = self.sync_every
+        next_sync = self.step + SYNC_EVERY
         while end is None or self.step < end:
+            if self.step >= next_sync:
+                torch.cuda.synchronize(self.device)
+                next_sync = self.step + SYNC_EVERY
             if stop_event is not None:
                 # data-parallel ranks leave the loop TOGETHER (the step contains collectives): the request is agreed on
                 # every stop_period steps; a single learner looks at its own flag every step

@@ -143,8 +143,18 @@ def main(argv=None) -> int:
             s0, t0_ = learner.step, time.time()
             while time.time() - t0_ < args.seconds / 2:
                 time.sleep(min(30.0, max(0.0, args.seconds / 2 - (time.time() - t0_))))
-                print("[system_bench] %.0f s: learner step %d, %d items ingested" % (time.time() - marks["t0"], learner.step,
-                                                                                      learner.ingested), file=sys.stderr, flush=True)
+                print("[system_bench] %.0f s: learner step %d, %d items ingested, replay %d, rss MB %s" % (
+                    time.time() - marks["t0"], learner.step, learner.ingested, len(learner.replay), rss_mb()), file=sys.stderr, flush=True)
+                if os.environ.get("SYSBENCH_DEBUG"):
+                    import gc
+                    import psutil
+                    mi = psutil.Process(os.getpid()).memory_info()
+                    print("    learner rss %d MB of which shared (shm segments, file pages) %d MB" % (mi.rss >> 20, mi.shared >> 20),
+                          file=sys.stderr, flush=True)
+                    print("    py objects %d, ring blocks %d, staged/retired/copying %d/%d/%d, cuda alloc %.0f MB, reserved %.0f MB" % (
+                        len(gc.get_objects()), len(learner.replay._blocks), len(learner.pipe._staged), len(learner.pipe._retired),
+                        len(learner.pipe._copying), torch.cuda.memory_allocated() / 2 ** 20, torch.cuda.memory_reserved() / 2 ** 20),
+                        file=sys.stderr, flush=True)
             halves.append(round((learner.step - s0) / (time.time() - t0_)))
         marks["halves"] = halves
         marks["rss_b"] = rss_mb()
