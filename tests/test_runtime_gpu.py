@@ -210,6 +210,17 @@ def test_r2d2_actor_engine_matches_module():
                             torch.from_numpy(done), torch.from_numpy(lengths), torch.from_numpy(h0).to(torch.bfloat16).float(),
                             torch.from_numpy(c0), None, cfg.eta, cfg.gamma_n, cfg.rescale_eps, require_grad=False)
     np.testing.assert_allclose(pr, td.prio.numpy(), rtol=0.1, atol=0.03)
+    # the same from a plane pool + window positions (codec kind 4): one staging image / one DMA per block; pools of different
+    # sizes and blocks of fewer sequences reuse the buffers
+    for M, k in ((300, K), (1500, K), (200, 3)):
+        planes = rng.integers(0, 256, (M, 84, 84), dtype=np.uint8)
+        win = rng.integers(0, M - 3, (k, T))
+        fr = np.ascontiguousarray(np.transpose(planes[win.T[:, :, None] + np.arange(4)], (0, 1, 3, 4, 2)))      # (T, k, 84, 84, 4)
+        pr_planes = eng.sequence_priorities_planes(planes, win, np.ascontiguousarray(action.T[:k]), np.ascontiguousarray(reward.T[:k]),
+                                                   np.ascontiguousarray(done.T[:k]), lengths[:k], h0[:k], c0[:k])
+        pr_frames = eng.sequence_priorities(fr, action[:, :k], reward[:, :k], done[:, :k], lengths[:k], h0[:k], c0[:k])
+        assert pr_planes.shape == (k,)
+        np.testing.assert_allclose(pr_planes, pr_frames, rtol=2e-2, atol=2e-3)
     # parameter refresh also refreshes the actor-side target
     from distributed_rl_amd.models import ParamPack
     m2 = DuelingLSTMDQN(A, E, cfg.burn_in, cfg.nstep)
