@@ -735,8 +735,10 @@ def conv_dgrad(layer: int, dy: torch.Tensor, w: torch.Tensor, act_in: Optional[t
 # body configuration of the fused launches (see drl_fc_bwd / drl_conv_bwd), measured at B = 512 (scripts/kbench.py --only
 # fused): fc1 38.6 us with both ring-4 bodies -> 29.7 us with ring-2 bodies, dW issued first (fewer VGPRs: more
 # resident workgroups for BOTH bodies); conv2 40.5 -> 29.8 us with a 64-deep ring-2 wgrad body issued first (32 KB LDS
-# instead of 64 KB for every workgroup of the launch); conv3 25.2 -> 24.6 us.
-FC_BWD_VARIANT = 5
+# instead of 64 KB for every workgroup of the launch); conv3 25.2 -> 24.6 us. Round 3, with the riders of the FC launch in
+# front of its GEMM bodies: the dX tiles (K = 1024, the longer loop) before the dW tiles (K = 512) - 0.1899 -> 0.1868 ms per
+# step; the conv launches keep their order (scripts/debug/fc_order_ab.py, profiles/apex_riders_first_r3.txt).
+FC_BWD_VARIANT = 2
 CONV_BWD_VARIANT = {1: 0, 2: 4, 3: 2}
 
 
