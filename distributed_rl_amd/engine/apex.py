@@ -110,7 +110,7 @@ class ApexEngine(ShardedIS):
     MAILBOX = 32         # floats in front of the flat gradient in the communication buffer (2 per rank, 128-byte aligned)
 
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
-                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits: int = 32,
+                 init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits=(16, 16, 128),
                  halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True,
                  ride_norm: bool = True, steps_per_graph: int = 4):
         self.cfg, self.replay, self.dist = cfg, replay, dist
@@ -159,6 +159,9 @@ class ApexEngine(ShardedIS):
         self.halo_bwd = H.CONV_HALO_BWD and (B >= 1024 if halo_bwd is None else bool(halo_bwd))
         self.wt2 = torch.zeros(4, 32, 2, 2, 64, **bf)
         self.wt3 = torch.zeros(64, 3, 3, 64, **bf)
+        # split-K of the conv3 / conv2 / conv1 weight-gradient bodies (one int: conv3 = conv2 = n, conv1 = 4 n). At B = 512 with
+        # the riders of the launches in front: 32 / 32 / 128 (round 2) 0.1868 ms per step, 16 / 16 / 64: 0.1845, 16 / 16 / 128:
+        # 0.1810, 8 or 24 for conv3 / conv2 and 32 or 96 / 160+ for conv1 are worse (profiles/apex_riders_first_r3.txt)
         self.wgrad_splits = wgrad_splits
         seg = self.G.layout.segments["fc1.w"]
         self.keep = (seg.offset, seg.offset + seg.numel) if seg.offset % 4 == 0 and seg.numel % 4 == 0 else (0, 0)
@@ -241,25 +244,26 @@ class ApexEngine(ShardedIS):
         B, r = self.B, self.replay
         G, Pb, on = self.G, self.Pb, self.on
         a2, a1 = on.act2[:B], on.act1[:B]
-        sp = self.wgrad_splits
+        ws = self.wgrad_splits                                 # split-K of the weight-gradient bodies: one count (conv3 = conv2,
+        sp3, sp2, sp1 = ws if isinstance(ws, (tuple, list)) else (ws, ws, 4 * ws)     # conv1 4 x) or (conv3, conv2, conv1)
         # the PER priority write-back (needs only the TD kernel's output) rides along as an extra body: leaves + level 1
         # inside the conv3 launch, upper levels + step_end inside the conv2 launch
         halo = self.halo_bwd                                   # dX in the LDS-halo kernel, dW + db (+ extra) in k_multi
         if halo:
             H.conv_halo_dgrad(3, self.d3, self.wt3, a2, self.d2, B)
         H.conv_bwd(3, a2, self.d3, Pb.view("conv3.w"), G.view("conv3.w"), G.view("conv3.b"), None if halo else self.d2,
-                   B, splits=sp, extra=r.update_stage(1, self.new_prio))
+                   B, splits=sp3, extra=r.update_stage(1, self.new_prio))
         if halo:
             H.conv_halo_dgrad(2, self.d2, self.wt2, a1, self.d1, B)
         H.conv_bwd(2, a1, self.d2, Pb.view("conv2.w"), G.view("conv2.w"), G.view("conv2.b"), None if halo else self.d1,
-                   B, splits=sp, extra=r.update_stage(2, self.new_prio, end_state=self.st,
+                   B, splits=sp2, extra=r.update_stage(2, self.new_prio, end_state=self.st,
                                                       sumsq=self._sq_big if self.ride_norm else None,
                                                       zero=G.flat[:self._late] if self.ride_norm else None))
         # presample: the PER batch of the NEXT step is drawn by extra blocks of this launch (the tree update and
         # step_end ran in the two launches before it) into the replay's next-batch buffers; the sampler's chain of
         # dependent tree reads hides here instead of opening the step. The optimizer launch hands the batch over.
         H.conv_bwd(1, r.frames, self.d1, None, G.view("conv1.w"), G.view("conv1.b"), None, B, frame_off=r.frame_off,
-                   splits=4 * sp, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None,
+                   splits=sp1, sample=r.sample_extra(self.st, 1.0, self.n_is) if self.presample else None,
                    extra=H.tree_extra(0, sumsq=self._sq_small) if self.ride_norm else None)
         if self.mailbox is not None:      # this rank's max IS weight(s) -> mailbox, in front of the conv slice's all-reduce
             H.wmax_put(self.st, self.mailbox, self.dist.rank, self.world)

@@ -14,18 +14,19 @@ from distributed_rl_amd.replay.device_per import DevicePER  # noqa: E402
 
 rep = DevicePER(2_000_000, "cuda", batch_size=512, seed=1)
 rep.fill_synthetic(2_000_000, n_action=4, seed=0)
-# arguments: fc,conv1,conv2,conv3 variant tuples, e.g. 2,0,4,2
+# arguments: fc,conv1,conv2,conv3[,wgrad_splits] variant tuples, e.g. 2,0,4,2 or 2,0,4,2,48
 cfgs = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(5, 0, 4, 2), (2, 0, 4, 2)]
-for v, c1, c2, c3 in cfgs:
+for v, c1, c2, c3, *rest in cfgs:
+    sp = (rest[0] if len(rest) == 1 else tuple(rest)) if rest else 32
     H.FC_BWD_VARIANT = v
     H.CONV_BWD_VARIANT = {1: c1, 2: c2, 3: c3}
     torch.manual_seed(0)
-    e = ApexEngine(4, ApexConfig(batch_size=512), rep, "cuda")
+    e = ApexEngine(4, ApexConfig(batch_size=512), rep, "cuda", wgrad_splits=sp)
     e.step()
     e.run_steps(400)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e.run_steps(2000)
     torch.cuda.synchronize()
-    print("variants fc %d conv1 %d conv2 %d conv3 %d: %.4f ms/step" % (v, c1, c2, c3, 1e3 * (time.perf_counter() - t0) / 2000), flush=True)
+    print("variants fc %d conv1 %d conv2 %d conv3 %d splits %s: %.4f ms/step" % (v, c1, c2, c3, sp, 1e3 * (time.perf_counter() - t0) / 2000), flush=True)
     del e
