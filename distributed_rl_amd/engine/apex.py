@@ -112,7 +112,7 @@ class ApexEngine(ShardedIS):
     def __init__(self, n_action: int, cfg: ApexConfig, replay: DevicePER, device="cuda", dist=None,
                  init_model: Optional[DuelingDQN] = None, use_graph: bool = True, wgrad_splits=(16, 16, 128),
                  halo_bwd: Optional[bool] = None, overlap_comm: bool = True, presample: bool = True,
-                 ride_norm: bool = True, steps_per_graph: int = 4):
+                 ride_norm: bool = True, steps_per_graph: int = 4, ride_blocks: int = 512):
         self.cfg, self.replay, self.dist = cfg, replay, dist
         self.device = torch.device(device)
         self.A = n_action
@@ -192,7 +192,8 @@ class ApexEngine(ShardedIS):
         o2, o3 = lay.offset("conv2.w"), lay.offset("conv3.w")
         self._ride_ok = (ride_norm and not self._dist_on() and o2 % 4 == 0 and o3 % 4 == 0 and lay.total % 4 == 0
                          and (self.G.flat.data_ptr() + 4 * o3) % 16 == 0)
-        nb, ns = 512, 16
+        nb, ns = int(ride_blocks), 16                      # workgroups that square [conv3.w, end) / [conv2.w, conv3.w)
+        assert 1 <= nb <= self.partial.numel() - ns
         self._sq_big = (self.G.flat[o3:], self.partial[:nb])
         self._sq_small = (self.G.flat[o2:o3], self.partial[nb:nb + ns])
         self._late = o2

@@ -21,7 +21,8 @@ for v, c1, c2, c3, *rest in cfgs:
     H.FC_BWD_VARIANT = v
     H.CONV_BWD_VARIANT = {1: c1, 2: c2, 3: c3}
     torch.manual_seed(0)
-    e = ApexEngine(4, ApexConfig(batch_size=512), rep, "cuda", wgrad_splits=sp)
+    e = ApexEngine(4, ApexConfig(batch_size=512), rep, "cuda", wgrad_splits=sp, ride_blocks=int(os.environ.get("RB", "512")),
+                   steps_per_graph=int(os.environ.get("KG", "4")))
     e.step()
     e.run_steps(400)
     torch.cuda.synchronize()
