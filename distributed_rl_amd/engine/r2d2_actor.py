@@ -25,6 +25,7 @@ from ..config import R2D2Config
 from ..models import DuelingLSTMDQN
 from ..models.packing import ParamPack, conv1_hwc, r2d2_layout
 from ..ops import hip as H
+from .apex import torso_net
 from .streams import capture_graph
 from ..utils import epsilon_ladder
 from .r2d2 import SeqNetBuffers, seq_net_forward
@@ -121,9 +122,12 @@ class R2D2ActorEngine:
     def _launch(self) -> None:
         E, Hd, wb, wf = self.E, self.Hd, self.Pb, self.P
         H.step_begin(self.st, self._n)               # advances the Philox counter on device
-        H.conv_fwd(1, self.obs, self.w1, wf.view("conv1.b"), self.act1, E)
-        H.conv_fwd(2, self.act1, wb.view("conv2.w"), wf.view("conv2.b"), self.act2, E)
-        H.conv_fwd(3, self.act2, wb.view("conv3.w"), wf.view("conv3.b"), self.act3, E)
+        if H.TORSO_FUSED:                            # conv1 -> conv2 -> conv3 as ONE launch (conv_torso.hip), as the Ape-X actor does
+            H.torso_fwd(self.obs, torso_net(self.__dict__.setdefault("_torso", {}), None, E, wb, wf, None, None, self.act3, w1=self.w1))
+        else:
+            H.conv_fwd(1, self.obs, self.w1, wf.view("conv1.b"), self.act1, E)
+            H.conv_fwd(2, self.act1, wb.view("conv2.w"), wf.view("conv2.b"), self.act2, E)
+            H.conv_fwd(3, self.act2, wb.view("conv3.w"), wf.view("conv3.b"), self.act3, E)
         H.add2(wf.view("lstm.b_ih"), wf.view("lstm.b_hh"), self.bsum)
         H.gemm(H.NT, self.act3, wb.view("lstm.w_ih"), self.xg, E, 4 * Hd, 3136, bias=self.bsum, flags=H.EPI_OUT_F32,
                big=E >= 1024)
